@@ -1,0 +1,194 @@
+/* veex.h -- C-ABI of libveex.so: the MI355X (gfx950) implementation of the VAE / autoencoder
+ * hot path of alessandroquirile/VAE-EEG-XAI.
+ *
+ * The reference has no FFI: its boundary is the Python class API of models.py /
+ * models_standard.py, underneath which TensorFlow/Keras kernels run.  Each entry point below
+ * therefore cites the reference lines whose Keras call it replaces.  The Python side
+ * (vae_eeg_xai_amd/) binds these symbols with ctypes and keeps the reference's class API.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 data unless named host_*; the caller owns all
+ *    memory; nothing here allocates, frees or synchronises; every kernel is enqueued on the
+ *    hipStream_t passed in (so calls can be captured into a HIP graph);
+ *  - return 0 on success, negative VEEX_E* otherwise; veex_last_error() returns a
+ *    thread-local message;
+ *  - activations are NHWC, weights have the Keras shapes of the reference:
+ *    Conv2D (kh,kw,Cin,Cout), Conv2DTranspose (kh,kw,Cout,Cin), Dense (in,out).
+ */
+#ifndef VEEX_H
+#define VEEX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* veexStream_t; /* == hipStream_t */
+
+#define VEEX_OK 0
+#define VEEX_EINVAL (-1)
+#define VEEX_ENOMEM (-2)   /* caller-provided workspace too small */
+#define VEEX_ELAUNCH (-3)
+
+#define VEEX_VARIANT_VAE 0 /* models.py: Encoder / Decoder / VAE */
+#define VEEX_VARIANT_AE 1  /* models_standard.py: EncoderStandard / DecoderStandard / Autoencoder */
+
+const char* veex_last_error(void);
+int veex_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Operator level
+ * ---------------------------------------------------------------------------------------- */
+
+/* Implicit-GEMM convolution family on the fp32 matrix cores.
+ * mode 0 "conv-gather"  : in = stride*out + k - pad_begin.  Conv2D forward (models.py:219-235,
+ *                         models_standard.py:89-105), Dense forward (models.py:238-241,264),
+ *                         Conv2DTranspose input-gradient (tape.gradient, models.py:166).
+ *                         Weight memory [tap][Cin][Cout].
+ * mode 1 "deconv-gather": in = (out + pad_begin - k)/stride.  Conv2DTranspose forward
+ *                         (models.py:270-298), Conv2D / Dense input-gradient.
+ *                         Weight memory [tap][Cout][Cin].
+ * pad_begin is TF's SAME pad-before of the (corresponding forward) convolution, i.e. the
+ * crop-at-start of a Conv2DTranspose.
+ * epilogue 0: out = relu?(acc + bias)            (the Keras layer's bias + activation)
+ * epilogue 1: BatchNorm(inference)/ReLU backward of the producing layer:
+ *             out = (aux > 0) ? acc * e_scale[c] : 0, column sums of acc, acc*aux, masked acc
+ *             per m-tile into partials[m_tiles][3][Cout] (see veex_colsum_finalize)
+ * epilogue 2: raw split-K slabs out[nsplit][...] (sum with veex_slab_sum) */
+typedef struct VeexGemmDesc {
+  const float* in;       /* [N][Hin][Win][Cin] */
+  const float* weight;
+  float* out;            /* [N][Hout][Wout][Cout] */
+  const float* in_scale; /* optional BatchNorm affine of the producer, applied to in-bounds loads */
+  const float* in_shift;
+  const float* bias;     /* epilogue 0, optional */
+  const float* aux;      /* epilogue 1 */
+  const float* e_scale;  /* epilogue 1, optional */
+  float* partials;       /* epilogue 1, optional */
+  int32_t N, Hin, Win, Cin, Hout, Wout, Cout;
+  int32_t kh, kw, stride, pad_begin;
+  int32_t mode;
+  int32_t affine_channels; /* power of two; index = (ci [+ pixel*Cin]) & (affine_channels-1) */
+  int32_t affine_spatial;  /* 1: BatchNorm ran over the flattened (h,w,c) vector (models.py:263-268) */
+  int32_t epilogue, relu;
+  int32_t e_channels;      /* epilogue 1: e_scale index = col & (e_channels-1) */
+  int32_t nsplit;          /* epilogue 2 */
+} VeexGemmDesc;
+int veex_gather_gemm(const VeexGemmDesc* d, veexStream_t stream);
+/* rows of the partials slab an epilogue-1 launch of this descriptor writes */
+int veex_gather_gemm_m_tiles(const VeexGemmDesc* d);
+
+/* Weight gradient (tape.gradient wrt kernel, models.py:166):
+ *   dW[tap][cb][cs] = sum_{n,py,px} big(n, stride*py+ky-pad_begin, stride*px+kx-pad_begin, cb) * small(n,py,px,cs)
+ * Conv2D: big = layer input, small = d(pre-activation); Conv2DTranspose: big = d(pre-act), small = input.
+ * out: [nsplit][kh*kw*Cb][Cs] slabs (nsplit==1: the gradient). rows_per_split multiple of 16. */
+typedef struct VeexWgradDesc {
+  const float* big;
+  const float* small;
+  float* out;
+  const float* big_scale; const float* big_shift;     /* optional producer BatchNorm affine */
+  const float* small_scale; const float* small_shift;
+  int32_t big_affine_channels, big_affine_spatial, small_affine_channels, small_affine_spatial;
+  int32_t N, Hb, Wb, Cb, Hs, Ws, Cs;
+  int32_t kh, kw, stride, pad_begin;
+  int32_t nsplit, rows_per_split;
+} VeexWgradDesc;
+int veex_wgrad_gemm(const VeexWgradDesc* d, veexStream_t stream);
+
+/* conv1 of the encoder, Conv2D(64,3,strides=2,'same',relu) on the 40x40x1 map (models.py:219-221). */
+int veex_conv1_fwd(const float* x, const float* w, const float* bias, float* out, int batch, veexStream_t s);
+int veex_conv1_wgrad_blocks(int batch);
+int veex_conv1_wgrad(const float* x, const float* dpre, float* slab /*[blocks][576]*/, int batch, veexStream_t s);
+/* d/dx through conv1 (attribution; no reference call site); mul != NULL gives gradient*input */
+int veex_conv1_dgrad(const float* dpre, const float* w, const float* mul, float* dx, int batch, veexStream_t s);
+
+/* deconv6 = Conv2DTranspose(1,2,'valid',sigmoid) (models.py:300-301) fused with
+ * keras.losses.binary_crossentropy + reduce_sum(axis=(1,2)) (models.py:156-160).
+ * Any of logits/recon/dlogit/rec_b/dlsum_b/target may be NULL. dlogit = (sigmoid-target)*inv_batch. */
+int veex_deconv6_bce_fwd(const float* a5, const float* scale, const float* shift, const float* w6, const float* b6,
+                         const float* target, float* logits, float* recon, float* dlogit, float* rec_b,
+                         float* dlsum_b, int batch, float inv_batch, veexStream_t s);
+/* backward of deconv6 fused with BatchNorm/ReLU backward of deconv5; slab [batch][7][64]:
+ * rows 0-3 dW6 partials, rows 4-6 the three column sums of veex_colsum_finalize */
+int veex_deconv6_bwd(const float* dlogit, const float* a5, const float* scale, const float* shift, const float* w6,
+                     float* dpre5, float* slab, int batch, veexStream_t s);
+
+/* sample() (models.py:10-22) fused with the analytic KL term (models.py:161-162).
+ * mulv = [B][2L] (z_mean | z_log_var). use_philox=0: eps is read (injected epsilon);
+ * use_philox=1: eps is generated (Philox-4x32-10 + Box-Muller, counter = global element index)
+ * and written back for the backward pass. */
+int veex_reparam_kl_fwd(const float* mulv, float* eps, float* z, float* kl_b, int batch, int latent, int use_philox,
+                        unsigned long long seed, unsigned long long first_sample, veexStream_t s);
+int veex_reparam_kl_bwd(const float* dz, const float* mulv, const float* eps, float* dmulv, int batch, int latent,
+                        float inv_batch, veexStream_t s);
+
+/* BatchNormalization in inference mode (models.py:222 etc.): scale = gamma/sqrt(var+eps),
+ * shift = beta - mean*scale, rstd = 1/sqrt(var+eps) */
+int veex_bn_prepare(const float* gamma, const float* beta, const float* mean, const float* var, float* scale,
+                    float* shift, float* rstd, int n, float eps, veexStream_t s);
+int veex_bnrelu_bwd_rows_chunks(int rows);
+int veex_bnrelu_bwd_rows(const float* g, const float* aux, const float* e_scale, float* out, float* partials,
+                         int rows, int cols, int e_channels, veexStream_t s);
+int veex_colsum_finalize(const float* partials, int T, long long row_stride, int ncols, int nch, const float* e_scale,
+                         const float* mean, const float* rstd, float* dbias, float* dgamma, float* dbeta,
+                         veexStream_t s);
+int veex_slab_sum(const float* slab, int nsplit, long long stride, long long n, float* out, const float* bias,
+                  int ncols, int relu, veexStream_t s);
+
+/* keras.optimizers.legacy.Adam (train.py:9,137,193): p -= alpha_t*m/(sqrt(v)+eps), alpha_t =
+ * lr*sqrt(1-b2^t)/(1-b1^t); step[0] (device int) is incremented; gscale multiplies g (1/world). */
+int veex_adam(float* p, const float* g, float* m, float* v, long long n, int* step, float* alpha, float lr,
+              float gscale, float b1, float b2, float eps, veexStream_t s);
+
+/* ------------------------------------------------------------------------------------------
+ * Network level: the whole Encoder / Decoder / VAE.train_step graph as one enqueue.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct VeexNet VeexNet; /* host-side plan only; owns no device memory */
+
+VeexNet* veex_net_create(int latent_dim, int variant);
+void veex_net_destroy(VeexNet* net);
+long long veex_net_param_floats(const VeexNet* net);  /* trainable flat buffer (multiple of 4) */
+long long veex_net_state_floats(const VeexNet* net);  /* BatchNorm moving mean | var */
+int veex_net_num_tensors(const VeexNet* net);
+/* tensor i in Keras get_weights() order (trainable first). offset is into the trainable buffer
+ * (trainable=1) or the state buffer (trainable=0). For the VAE the two latent heads are stored
+ * as one [100][2L] matrix: part = 0 whole tensor, 1 = columns [0,L), 2 = columns [L,2L). */
+int veex_net_tensor_info(const VeexNet* net, int i, char* name, int name_cap, long long* offset, int* ndim,
+                         long long* shape4, int* trainable, int* part);
+long long veex_net_workspace_floats(const VeexNet* net, int batch);
+/* named workspace regions (activations "act.<layer>", gradients "dpre.<layer>", "z", "mulv", "eps", ...) for tests */
+long long veex_net_ws_offset(const VeexNet* net, int batch, const char* name, long long* nfloats);
+
+#define VEEX_F_PHILOX 1      /* generate epsilon on device (else read it from the eps argument) */
+#define VEEX_F_ZMEAN_DECODE 2 /* decode z_mean instead of the sampled z (not the reference's VAE.call) */
+
+/* Encoder.call (models.py:244-253) / EncoderStandard.call (models_standard.py:110-116).
+ * outputs (nullable): z_mean [B][L], z_log_var [B][L], z [B][L] (AE: z = bottleneck, others unused) */
+int veex_net_encode(const VeexNet* net, const float* params, const float* state, const float* x, float* eps_io,
+                    int batch, int flags, unsigned long long seed, unsigned long long first_sample, float* ws,
+                    long long ws_floats, float* z_mean, float* z_log_var, float* z, veexStream_t s);
+/* Decoder.call (models.py:303-312): z [B][L] -> recon [B][40][40][1] (and/or logits) */
+int veex_net_decode(const VeexNet* net, const float* params, const float* state, const float* z, int batch, float* ws,
+                    long long ws_floats, float* recon, float* logits, veexStream_t s);
+/* VAE.call / test_step (models.py:135-138,182-207): forward + losses. losses[3] = total, rec, kl;
+ * metrics[4] (nullable) += losses, count */
+int veex_net_forward(const VeexNet* net, const float* params, const float* state, const float* x, float* eps_io,
+                     int batch, int flags, unsigned long long seed, unsigned long long first_sample, float* ws,
+                     long long ws_floats, float* recon, float* losses, float* metrics, veexStream_t s);
+/* VAE.train_step up to tape.gradient (models.py:148-166): forward, losses, all gradients into
+ * grads (same layout as params). The optimizer step is veex_adam on the flat buffers, after the
+ * caller's (optional) all-reduce of grads. */
+int veex_net_train_fwd_bwd(const VeexNet* net, const float* params, const float* state, const float* x, float* eps_io,
+                           int batch, int flags, unsigned long long seed, unsigned long long first_sample, float* ws,
+                           long long ws_floats, float* grads, float* losses, float* metrics, veexStream_t s);
+/* Gradient attribution (north_star item 3; no reference call site): out[u][b][40][40] =
+ * d z_mean[b][units[u]] / d x[b]  (AE: the bottleneck unit), times x when grad_x_input. */
+int veex_net_attribute(const VeexNet* net, const float* params, const float* state, const float* x, int batch,
+                       const int* host_units, int n_units, int grad_x_input, float* ws, long long ws_floats,
+                       float* out, veexStream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VEEX_H */

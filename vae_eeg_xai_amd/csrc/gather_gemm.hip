@@ -1,0 +1,405 @@
+// Implicit-GEMM engine on the exact-fp32 matrix cores of gfx950
+// (v_mfma_f32_32x32x2_f32: bit-exact k-ordered fmaf chain, 64 FLOP/clk/SIMD).
+//
+// One kernel template serves every dense contraction of the VAE hot path that is not a
+// weight gradient:
+//   mode 0 "conv-gather":   Conv2D forward (reference models.py:219-235), Dense forward
+//                           (models.py:238-241,264), Conv2DTranspose input-gradient
+//   mode 1 "deconv-gather": Conv2DTranspose forward (models.py:270-298), Conv2D / Dense
+//                           input-gradient.  Stride 2 is decomposed into 4 sub-pixel phases so
+//                           that no MFMA is spent on the zeros of a zero-inserted input.
+//
+// Data layout: activations NHWC in HBM (channel-contiguous = GEMM-K contiguous), weights in
+// the Keras shapes the reference uses ((kh,kw,Cin,Cout) / (kh,kw,Cout,Cin) / (in,out)).
+// A tile [BM][16] and B tile are register-staged into double-buffered LDS (one barrier per
+// K-chunk); the producer layer's BatchNorm (inference mode) is applied to A while
+// staging, so every activation is stored once (post-ReLU) and read once per tap.
+// Epilogues: FWD = +bias, ReLU;  BWD = BatchNorm/ReLU backward of the layer whose output
+// gradient this GEMM produces (writes d(pre-activation) and per-tile column sums for dgamma,
+// dbeta, dbias);  RAW = split-K partial slab.
+#include "veex_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float4 ld4(const float* ptr, bool ok, int nvalid, bool vec) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) {
+    if (vec && nvalid >= 4) {
+      v = *reinterpret_cast<const float4*>(ptr);
+    } else {
+      if (nvalid > 0) v.x = ptr[0];
+      if (nvalid > 1) v.y = ptr[1];
+      if (nvalid > 2) v.z = ptr[2];
+      if (nvalid > 3) v.w = ptr[3];
+    }
+  }
+  return v;
+}
+
+template <int BM, int BN, int WM, int WN, bool MODE1>
+__global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MT = WTM / 32, NT = WTN / 32;
+  constexpr int APASS = BM / 64;
+  constexpr int A_ELEMS = BM * VEEX_LDK;
+  constexpr int LDN = BN + 4;
+  constexpr int B_ELEMS = MODE1 ? BN * VEEX_LDK : VEEX_BK * LDN;
+  constexpr int BPASS = MODE1 ? BN / 64 : (VEEX_BK * BN / 4) / 256;
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(BPASS >= 1, "tile too small");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * A_ELEMS;
+  int* s_off = reinterpret_cast<int*>(Bs + 2 * B_ELEMS);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lh = lane >> 5, l31 = lane & 31;
+
+  // ---- block -> (phase, m tile, n tile, k split) ----
+  int tile = blockIdx.x, ph = 0;
+  if (p.nphase == 4) {
+    while (ph < 3 && tile >= p.tile_prefix[ph + 1]) ++ph;
+  }
+  const int py = ph >> 1, px = ph & 1;
+  const int Hp = p.Hp[py], Wp = p.Wp[px];
+  const int ostep = (p.nphase == 4) ? 2 : 1;
+  const int oy0 = p.o0[py], ox0 = p.o0[px];
+  const int Mph = p.Nb * Hp * Wp;
+  const int m0 = (tile - p.tile_prefix[ph]) * BM;
+  const int n0 = blockIdx.y * BN;
+
+  int kys = 0, kxs = 0, kstep = 1, nky = p.kh, nkx = p.kw;
+  if (p.nphase == 4) {
+    kys = py; kxs = px; kstep = 2;
+    nky = (p.kh - py + 1) >> 1;
+    nkx = (p.kw - px + 1) >> 1;
+  }
+  const int cpt = (p.Cin + VEEX_BK - 1) / VEEX_BK;
+  const int nchunks = nky * nkx * cpt;
+  const int c_begin = blockIdx.z * p.chunks_per_split;
+  const int c_end = min(nchunks, c_begin + p.chunks_per_split);
+
+  const int HWp = Hp * Wp;
+  // output offsets (pixel index) of the tile rows, for the epilogue
+  if (tid < BM) {
+    int m = m0 + tid, off = -1;
+    if (m < Mph) {
+      int n = m / HWp, rem = m - n * HWp;
+      int j = rem / Wp, i = rem - j * Wp;
+      off = (n * p.Hout + ostep * j + oy0) * p.Wout + ostep * i + ox0;
+    }
+    s_off[tid] = off;
+  }
+
+  // ---- loader state: this thread stages rows (tid>>2)+64*i, k-quad (tid&3) of the A tile ----
+  const int q = tid & 3, lr = tid >> 2;
+  int a_base[APASS], a_y[APASS], a_x[APASS];
+#pragma unroll
+  for (int i = 0; i < APASS; ++i) {
+    int m = m0 + lr + 64 * i;
+    a_base[i] = -1; a_y[i] = 0; a_x[i] = 0;
+    if (m < Mph) {
+      int n = m / HWp, rem = m - n * HWp;
+      int j = rem / Wp, ii = rem - j * Wp;
+      int oy = ostep * j + oy0, ox = ostep * ii + ox0;
+      a_base[i] = n * p.Hin * p.Win;
+      if (MODE1) { a_y[i] = oy + p.pb; a_x[i] = ox + p.pb; }
+      else       { a_y[i] = p.stride * oy - p.pb; a_x[i] = p.stride * ox - p.pb; }
+    }
+  }
+  const bool vecA = ((p.Cin & 3) == 0);
+  const bool vecW = MODE1 ? vecA : ((p.Cout & 3) == 0);
+  const int sshift = p.stride - 1;   // stride in {1,2}
+
+  float4 ra[APASS], rb[BPASS];
+
+  auto load_chunk = [&](int c) {
+    const int tapi = c / cpt;
+    const int cc = c - tapi * cpt;
+    const int ia = tapi / nkx, ib = tapi - ia * nkx;
+    const int ky = kys + kstep * ia, kx = kxs + kstep * ib;
+    const int tap = ky * p.kw + kx;
+    const int ci0 = cc * VEEX_BK;
+    const int ci = ci0 + 4 * q;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      bool ok = a_base[i] >= 0;
+      int iy, ix;
+      if (MODE1) {
+        int ty = a_y[i] - ky, tx = a_x[i] - kx;
+        ok = ok && ty >= 0 && tx >= 0;
+        iy = ty >> sshift; ix = tx >> sshift;
+      } else {
+        iy = a_y[i] + ky; ix = a_x[i] + kx;
+      }
+      ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win && ci < p.Cin;
+      const int pix = iy * p.Win + ix;
+      const float* ptr = p.A + ((long long)(a_base[i] + pix)) * p.Cin + ci;
+      float4 v = ld4(ptr, ok, p.Cin - ci, vecA);
+      if (p.a_scale != nullptr && ok) {
+        const int aidx = (ci + (p.aff_spatial ? pix * p.Cin : 0)) & p.aff_mask;
+        const float4 sc = ld4(p.a_scale + aidx, true, p.Cin - ci, vecA);
+        const float4 sh = ld4(p.a_shift + aidx, true, p.Cin - ci, vecA);
+        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+        v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+        // lanes beyond Cin keep 0: scale/shift loads there returned 0 too
+      }
+      ra[i] = v;
+    }
+    if (MODE1) {
+#pragma unroll
+      for (int i = 0; i < BPASS; ++i) {
+        const int n = n0 + lr + 64 * i;
+        const bool ok = n < p.Cout && ci < p.Cin;
+        const float* ptr = p.W + ((long long)tap * p.Cout + n) * p.Cin + ci;
+        rb[i] = ld4(ptr, ok, p.Cin - ci, vecW);
+      }
+    } else {
+      constexpr int QN = BN / 4;
+      constexpr int RPP = 256 / QN;
+      const int nq = tid % QN, kr = tid / QN;
+#pragma unroll
+      for (int i = 0; i < BPASS; ++i) {
+        const int k = kr + RPP * i;
+        const int cik = ci0 + k;
+        const int n = n0 + 4 * nq;
+        const bool ok = cik < p.Cin && n < p.Cout;
+        const float* ptr = p.W + ((long long)tap * p.Cin + cik) * p.Cout + n;
+        rb[i] = ld4(ptr, ok, p.Cout - n, vecW);
+      }
+    }
+  };
+
+  auto store_chunk = [&](int buf) {
+    float* as = As + buf * A_ELEMS;
+    float* bs = Bs + buf * B_ELEMS;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i)
+      *reinterpret_cast<float4*>(as + (lr + 64 * i) * VEEX_LDK + 4 * q) = ra[i];
+    if (MODE1) {
+#pragma unroll
+      for (int i = 0; i < BPASS; ++i)
+        *reinterpret_cast<float4*>(bs + (lr + 64 * i) * VEEX_LDK + 4 * q) = rb[i];
+    } else {
+      constexpr int QN = BN / 4;
+      constexpr int RPP = 256 / QN;
+      const int nq = tid % QN, kr = tid / QN;
+#pragma unroll
+      for (int i = 0; i < BPASS; ++i)
+        *reinterpret_cast<float4*>(bs + (kr + RPP * i) * LDN + 4 * nq) = rb[i];
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (c_begin < c_end) {
+    load_chunk(c_begin);
+    store_chunk(0);
+  }
+  __syncthreads();
+
+  for (int c = c_begin; c < c_end; ++c) {
+    const int cur = (c - c_begin) & 1;
+    const bool more = (c + 1 < c_end);
+    if (more) load_chunk(c + 1);
+    const float* as = As + cur * A_ELEMS + (wm * WTM + l31) * VEEX_LDK + 8 * lh;
+    const float* bs = MODE1 ? (Bs + cur * B_ELEMS + (wn * WTN + l31) * VEEX_LDK + 8 * lh)
+                            : (Bs + cur * B_ELEMS + (8 * lh) * LDN + wn * WTN + l31);
+    // K order inside a chunk is permuted: lanes 0-31 feed k = 0..7, lanes 32-63 k = 8..15
+    // (A and B use the same permutation, so the sum is unchanged).
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float av[MT][4], bv[NT][4];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const float4 t = *reinterpret_cast<const float4*>(as + i * 32 * VEEX_LDK + 4 * half);
+        av[i][0] = t.x; av[i][1] = t.y; av[i][2] = t.z; av[i][3] = t.w;
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (MODE1) {
+          const float4 t = *reinterpret_cast<const float4*>(bs + j * 32 * VEEX_LDK + 4 * half);
+          bv[j][0] = t.x; bv[j][1] = t.y; bv[j][2] = t.z; bv[j][3] = t.w;
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) bv[j][kk] = bs[(4 * half + kk) * LDN + j * 32];
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][kk], bv[j][kk], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_chunk(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float cs1[NT], cs2[NT], cs3[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { cs1[j] = 0.f; cs2[j] = 0.f; cs3[j] = 0.f; }
+
+  float* outp = p.Out;
+  if (p.epi == VEEX_EPI_RAW) outp += (long long)blockIdx.z * p.slab_stride;
+
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + wn * WTN + j * 32 + l31;
+    const bool colok = col < p.Cout;
+    float bia = 0.f, esc = 1.f;
+    if (colok) {
+      if (p.epi == VEEX_EPI_FWD && p.bias != nullptr) bia = p.bias[col];
+      if (p.epi == VEEX_EPI_BWD && p.e_scale != nullptr) esc = p.e_scale[col & p.epi_cmask];
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int off = s_off[rl];
+        if (off < 0 || !colok) continue;
+        const long long addr = (long long)off * p.Cout + col;
+        float v = acc[i][j][r];
+        if (p.epi == VEEX_EPI_FWD) {
+          v += bia;
+          if (p.relu) v = fmaxf(v, 0.f);
+          outp[addr] = v;
+        } else if (p.epi == VEEX_EPI_BWD) {
+          const float a = p.aux[addr];
+          const bool on = (!p.relu) || (a > 0.f);
+          cs1[j] += v;
+          cs2[j] = fmaf(v, a, cs2[j]);
+          cs3[j] += on ? v : 0.f;
+          outp[addr] = on ? v * esc : 0.f;
+        } else {
+          outp[addr] = v;
+        }
+      }
+    }
+  }
+
+  if (p.epi == VEEX_EPI_BWD && p.partials != nullptr) {
+    // column sums: lane halves -> waves sharing the columns (wm) -> one row of the partial slab
+    float* s_red = As;   // [WM][BN][3]; safe: every wave passed the loop's last barrier
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      cs1[j] += __shfl_xor(cs1[j], 32);
+      cs2[j] += __shfl_xor(cs2[j], 32);
+      cs3[j] += __shfl_xor(cs3[j], 32);
+      if (lh == 0) {
+        const int cl = wn * WTN + j * 32 + l31;
+        s_red[(wm * BN + cl) * 3 + 0] = cs1[j];
+        s_red[(wm * BN + cl) * 3 + 1] = cs2[j];
+        s_red[(wm * BN + cl) * 3 + 2] = cs3[j];
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.Cout) {
+      float t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        t1 += s_red[(w * BN + tid) * 3 + 0];
+        t2 += s_red[(w * BN + tid) * 3 + 1];
+        t3 += s_red[(w * BN + tid) * 3 + 2];
+      }
+      float* pp = p.partials + (long long)blockIdx.x * 3 * p.Cout + n0 + tid;
+      pp[0] = t1;
+      pp[p.Cout] = t2;
+      pp[2 * p.Cout] = t3;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+int veex_gg_bm(int Cout, long long M) {
+  (void)Cout;
+  return (M >= 4096) ? 128 : 64;
+}
+
+static int gg_bn(int Cout, int bm) {
+  if (bm == 64) return 64;
+  return (Cout > 64) ? 128 : 64;
+}
+
+int veex_gg_m_tiles(GGParams& p) {
+  const long long Mtot = (long long)p.Nb * p.Hout * p.Wout;
+  const int bm = veex_gg_bm(p.Cout, Mtot);
+  if (p.mode == 1 && p.stride == 2) {
+    p.nphase = 4;
+    for (int par = 0; par < 2; ++par) {
+      const int o0 = (par + p.pb) & 1;   // smallest o >= 0 with (o + pb) % 2 == par
+      p.o0[par] = o0;
+      p.Hp[par] = (p.Hout > o0) ? (p.Hout - o0 + 1) / 2 : 0;
+      p.Wp[par] = (p.Wout > o0) ? (p.Wout - o0 + 1) / 2 : 0;
+    }
+    p.tile_prefix[0] = 0;
+    for (int ph = 0; ph < 4; ++ph) {
+      const long long mph = (long long)p.Nb * p.Hp[ph >> 1] * p.Wp[ph & 1];
+      p.tile_prefix[ph + 1] = p.tile_prefix[ph] + (int)((mph + bm - 1) / bm);
+    }
+    return p.tile_prefix[4];
+  }
+  p.nphase = 1;
+  p.o0[0] = p.o0[1] = 0;
+  p.Hp[0] = p.Hp[1] = p.Hout;
+  p.Wp[0] = p.Wp[1] = p.Wout;
+  p.tile_prefix[0] = 0;
+  const int t = (int)((Mtot + bm - 1) / bm);
+  for (int ph = 1; ph <= 4; ++ph) p.tile_prefix[ph] = t;
+  return t;
+}
+
+template <int BM, int BN, int WM, int WN>
+static int gg_launch_cfg(const GGParams& p, int mtiles, hipStream_t st) {
+  const int ntiles = (p.Cout + BN - 1) / BN;
+  dim3 grid(mtiles, ntiles, p.nsplit);
+  if (p.mode == 1) {
+    constexpr size_t lds = (2 * BM * VEEX_LDK + 2 * BN * VEEX_LDK) * sizeof(float) + BM * sizeof(int);
+    hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, WM, WN, true>), grid, dim3(256), lds, st, p);
+  } else {
+    constexpr size_t lds = (2 * BM * VEEX_LDK + 2 * VEEX_BK * (BN + 4)) * sizeof(float) + BM * sizeof(int);
+    hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, WM, WN, false>), grid, dim3(256), lds, st, p);
+  }
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+int veex_launch_gather_gemm(const GGParams& pin, hipStream_t st) {
+  GGParams p = pin;
+  if (p.stride != 1 && p.stride != 2) { veex_set_error("gather_gemm: stride %d unsupported", p.stride); return -1; }
+  if (p.Nb <= 0 || p.Cin <= 0 || p.Cout <= 0 || p.Hout <= 0 || p.Wout <= 0 || p.Hin <= 0 || p.Win <= 0) {
+    veex_set_error("gather_gemm: bad geometry"); return -1;
+  }
+  if (p.kh * p.kw > 1 && (p.Cin % VEEX_BK) != 0) {
+    veex_set_error("gather_gemm: multi-tap layers need Cin %% 16 == 0 (got %d)", p.Cin); return -1;
+  }
+  if (p.a_scale && ((p.aff_mask + 1) & p.aff_mask)) { veex_set_error("gather_gemm: affine size must be a power of two"); return -1; }
+  const long long Mtot = (long long)p.Nb * p.Hout * p.Wout;
+  if (Mtot * p.Cout >= (1LL << 40) || Mtot >= (1LL << 31)) { veex_set_error("gather_gemm: problem too large"); return -1; }
+  const int mtiles = veex_gg_m_tiles(p);
+  if (p.nsplit < 1) p.nsplit = 1;
+  if (p.nsplit > 1 && (p.nphase != 1 || p.epi != VEEX_EPI_RAW)) {
+    veex_set_error("gather_gemm: split-K needs RAW epilogue and a single phase"); return -1;
+  }
+  if (p.nsplit == 1) p.chunks_per_split = 1 << 30;
+  const int bm = veex_gg_bm(p.Cout, Mtot);
+  const int bn = gg_bn(p.Cout, bm);
+  if (bm == 128 && bn == 128) return gg_launch_cfg<128, 128, 2, 2>(p, mtiles, st);
+  if (bm == 128 && bn == 64) return gg_launch_cfg<128, 64, 2, 2>(p, mtiles, st);
+  return gg_launch_cfg<64, 64, 2, 2>(p, mtiles, st);
+}

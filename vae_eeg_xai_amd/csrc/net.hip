@@ -1,0 +1,808 @@
+// Host-side plan of the reference network (models.py:211-312, models_standard.py:81-175) and the
+// whole-step entry points of the C-ABI: one call enqueues every kernel of Encoder.call,
+// Decoder.call, VAE.train_step (forward + loss + tape.gradient) or the attribution backward on
+// the caller's stream.  No allocation, no synchronisation: all device memory is the caller's.
+#include "veex_internal.h"
+#include "../../include/veex.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void veex_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* veex_last_error(void) { return g_err; }
+extern "C" int veex_abi_version(void) { return 1; }
+
+extern "C" int veexi_loss_finalize(const float*, const float*, const float*, int, float*, float*, float*, hipStream_t);
+extern "C" int veexi_attr_seed(const float*, const float*, float*, int, int, int, int, int, hipStream_t);
+
+#define TRY(x)            \
+  do {                    \
+    int rc__ = (x);       \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+static inline int pow2_or_zero(int c) { return (c > 0 && (c & (c - 1)) == 0); }
+
+// ------------------------------------------------------------------------------------------
+// operator-level wrappers (descriptor -> internal params)
+// ------------------------------------------------------------------------------------------
+static int fill_gg(const VeexGemmDesc* d, GGParams& p) {
+  if (d == nullptr) { veex_set_error("null descriptor"); return VEEX_EINVAL; }
+  memset(&p, 0, sizeof(p));
+  p.A = d->in; p.W = d->weight; p.Out = d->out;
+  p.a_scale = d->in_scale; p.a_shift = d->in_shift;
+  p.bias = d->bias; p.aux = d->aux; p.e_scale = d->e_scale; p.partials = d->partials;
+  p.Nb = d->N; p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin;
+  p.Hout = d->Hout; p.Wout = d->Wout; p.Cout = d->Cout;
+  p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pb = d->pad_begin;
+  p.mode = d->mode;
+  if (p.a_scale != nullptr) {
+    if (!pow2_or_zero(d->affine_channels) || p.a_shift == nullptr) {
+      veex_set_error("gather_gemm: affine_channels must be a power of two and in_shift non-null"); return VEEX_EINVAL;
+    }
+    p.aff_mask = d->affine_channels - 1;
+  }
+  p.aff_spatial = d->affine_spatial;
+  p.epi = d->epilogue; p.relu = d->relu;
+  if (p.epi == VEEX_EPI_BWD) {
+    if (p.aux == nullptr) { veex_set_error("gather_gemm: epilogue 1 needs aux"); return VEEX_EINVAL; }
+    if (p.e_scale != nullptr && !pow2_or_zero(d->e_channels)) {
+      veex_set_error("gather_gemm: e_channels must be a power of two"); return VEEX_EINVAL;
+    }
+    p.epi_cmask = (p.e_scale != nullptr) ? d->e_channels - 1 : 0;
+  }
+  if (p.mode != 0 && p.mode != 1) { veex_set_error("gather_gemm: mode must be 0 or 1"); return VEEX_EINVAL; }
+  if (p.A == nullptr || p.W == nullptr || p.Out == nullptr) { veex_set_error("gather_gemm: null operand"); return VEEX_EINVAL; }
+  p.nsplit = d->nsplit > 0 ? d->nsplit : 1;
+  if (p.epi != VEEX_EPI_RAW && p.nsplit != 1) { veex_set_error("gather_gemm: nsplit > 1 needs epilogue 2"); return VEEX_EINVAL; }
+  const int cpt = (p.Cin + VEEX_BK - 1) / VEEX_BK;
+  const int nchunks = p.kh * p.kw * cpt;
+  p.chunks_per_split = (nchunks + p.nsplit - 1) / p.nsplit;
+  p.slab_stride = (long long)p.Nb * p.Hout * p.Wout * p.Cout;
+  return 0;
+}
+
+extern "C" int veex_gather_gemm(const VeexGemmDesc* d, veexStream_t stream) {
+  GGParams p;
+  TRY(fill_gg(d, p));
+  return veex_launch_gather_gemm(p, stream);
+}
+
+extern "C" int veex_gather_gemm_m_tiles(const VeexGemmDesc* d) {
+  GGParams p;
+  if (fill_gg(d, p) != 0) return -1;
+  return veex_gg_m_tiles(p);
+}
+
+static int fill_wg(const VeexWgradDesc* d, WGParams& p) {
+  if (d == nullptr) { veex_set_error("null descriptor"); return VEEX_EINVAL; }
+  memset(&p, 0, sizeof(p));
+  p.Big = d->big; p.Small = d->small; p.Out = d->out;
+  p.b_scale = d->big_scale; p.b_shift = d->big_shift; p.s_scale = d->small_scale; p.s_shift = d->small_shift;
+  if (p.b_scale != nullptr) {
+    if (!pow2_or_zero(d->big_affine_channels)) { veex_set_error("wgrad: big_affine_channels must be a power of two"); return VEEX_EINVAL; }
+    p.b_aff_mask = d->big_affine_channels - 1;
+  }
+  if (p.s_scale != nullptr) {
+    if (!pow2_or_zero(d->small_affine_channels)) { veex_set_error("wgrad: small_affine_channels must be a power of two"); return VEEX_EINVAL; }
+    p.s_aff_mask = d->small_affine_channels - 1;
+  }
+  p.b_aff_spatial = d->big_affine_spatial; p.s_aff_spatial = d->small_affine_spatial;
+  p.Nb = d->N; p.Hb = d->Hb; p.Wb = d->Wb; p.Cb = d->Cb; p.Hs = d->Hs; p.Ws = d->Ws; p.Cs = d->Cs;
+  p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pb = d->pad_begin;
+  p.R = p.Nb * p.Hs * p.Ws;
+  p.M = p.kh * p.kw * p.Cb;
+  p.nsplit = d->nsplit; p.rows_per_split = d->rows_per_split;
+  if (p.Big == nullptr || p.Small == nullptr || p.Out == nullptr) { veex_set_error("wgrad: null operand"); return VEEX_EINVAL; }
+  return 0;
+}
+
+extern "C" int veex_wgrad_gemm(const VeexWgradDesc* d, veexStream_t stream) {
+  WGParams p;
+  TRY(fill_wg(d, p));
+  return veex_launch_wgrad(p, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// network plan
+// ------------------------------------------------------------------------------------------
+static const float BN_EPS = 1e-3f;  // keras BatchNormalization default
+
+struct TensorInfo {
+  std::string name;
+  long long offset;
+  int ndim;
+  long long shape[4];
+  int trainable;
+  int part;  // 0 whole, 1/2 = first/second half of the columns of the [100][2L] head matrix
+};
+
+struct ConvLayer {  // one Conv2D / Conv2DTranspose / Dense with optional BatchNorm after its ReLU
+  const char* name;
+  int Cin, Cout, k, stride, pb, Hin, Hout;
+  long long w, b;   // offsets into the trainable buffer
+  int bn;           // channel offset into the BN arrays, -1 = none
+  int bnC;
+};
+
+struct VeexNet {
+  int L, variant, H1;
+  long long n_params, n_state;
+  int n_bn;                     // total BatchNorm channels
+  long long gamma_off, beta_off;  // trainable buffer
+  std::vector<TensorInfo> tensors;
+  ConvLayer conv[3];    // encoder convs
+  ConvLayer dense;      // encoder dense (as 5x5 VALID conv over (5,5,256))
+  long long wh, bh;     // VAE heads [100][2L], [2L]
+  ConvLayer ddense;     // decoder dense L -> 4096
+  ConvLayer dc[6];      // decoder deconvs
+};
+
+static long long align4(long long v) { return (v + 3) & ~3LL; }
+static long long align64(long long v) { return (v + 63) & ~63LL; }
+
+extern "C" VeexNet* veex_net_create(int L, int variant) {
+  if (L < 1 || L > 4096 || (variant != VEEX_VARIANT_VAE && variant != VEEX_VARIANT_AE)) {
+    veex_set_error("net_create: bad latent_dim %d / variant %d", L, variant);
+    return nullptr;
+  }
+  VeexNet* n = new VeexNet();
+  n->L = L; n->variant = variant;
+  n->H1 = (variant == VEEX_VARIANT_VAE) ? 100 : L;
+  long long off = 0;
+  int bnoff = 0;
+  auto take = [&](long long cnt) { long long o = off; off = align4(off + cnt); return o; };
+  auto takebn = [&](int c) { int o = bnoff; bnoff += c; return o; };
+
+  // encoder convs (models.py:219-235): k3 s2 SAME -> pad_before 0 on even inputs
+  const int ecin[3] = {1, 64, 128}, ecout[3] = {64, 128, 256}, ehin[3] = {40, 20, 10};
+  const char* ename[3] = {"enc.conv1", "enc.conv2", "enc.conv3"};
+  for (int i = 0; i < 3; ++i) {
+    ConvLayer& c = n->conv[i];
+    c.name = ename[i]; c.Cin = ecin[i]; c.Cout = ecout[i]; c.k = 3; c.stride = 2; c.pb = 0;
+    c.Hin = ehin[i]; c.Hout = ehin[i] / 2;
+    c.w = take(9LL * c.Cin * c.Cout); c.b = take(c.Cout);
+    c.bn = takebn(c.Cout); c.bnC = c.Cout;
+  }
+  {
+    ConvLayer& c = n->dense;  // Dense(6400 -> H1, relu) (models.py:238 / models_standard.py:108)
+    c.name = "enc.dense"; c.Cin = 256; c.Cout = n->H1; c.k = 5; c.stride = 1; c.pb = 0; c.Hin = 5; c.Hout = 1;
+    c.w = take(6400LL * n->H1); c.b = take(n->H1); c.bn = -1; c.bnC = 0;
+  }
+  if (variant == VEEX_VARIANT_VAE) { n->wh = take(100LL * 2 * L); n->bh = take(2LL * L); }
+  else { n->wh = n->bh = -1; }
+  {
+    ConvLayer& c = n->ddense;  // Dense(L -> 4096, relu) + BN(4096) (models.py:263-266)
+    c.name = "dec.dense"; c.Cin = L; c.Cout = 4096; c.k = 1; c.stride = 1; c.pb = 0; c.Hin = 1; c.Hout = 1;
+    c.w = take((long long)L * 4096); c.b = take(4096); c.bn = takebn(4096); c.bnC = 4096;
+  }
+  // decoder deconvs (models.py:270-301); pb = crop-at-start
+  const int dcin[6] = {256, 256, 128, 128, 64, 64}, dcout[6] = {256, 128, 128, 64, 64, 1};
+  const int dk[6] = {3, 3, 3, 3, 3, 2}, ds[6] = {2, 1, 2, 1, 2, 1}, dpb[6] = {0, 1, 0, 0, 0, 0};
+  const int dhin[6] = {4, 8, 8, 17, 19, 39}, dhout[6] = {8, 8, 17, 19, 39, 40};
+  const char* dname[6] = {"dec.deconv1", "dec.deconv2", "dec.deconv3", "dec.deconv4", "dec.deconv5", "dec.deconv6"};
+  for (int i = 0; i < 6; ++i) {
+    ConvLayer& c = n->dc[i];
+    c.name = dname[i]; c.Cin = dcin[i]; c.Cout = dcout[i]; c.k = dk[i]; c.stride = ds[i]; c.pb = dpb[i];
+    c.Hin = dhin[i]; c.Hout = dhout[i];
+    c.w = take((long long)dk[i] * dk[i] * dcin[i] * dcout[i]); c.b = take(dcout[i]);
+    if (i < 5) { c.bn = takebn(c.Cout); c.bnC = c.Cout; } else { c.bn = -1; c.bnC = 0; }
+  }
+  n->n_bn = bnoff;
+  n->gamma_off = take(bnoff);
+  n->beta_off = take(bnoff);
+  n->n_params = off;
+  n->n_state = 2LL * bnoff;  // mean | var
+
+  // tensor table in Keras get_weights() order: trainable in layer-creation order, then moving stats
+  auto add = [&](const std::string& name, long long o, std::initializer_list<long long> shp, int tr, int part = 0) {
+    TensorInfo t; t.name = name; t.offset = o; t.ndim = (int)shp.size(); t.trainable = tr; t.part = part;
+    int i = 0; for (long long s : shp) t.shape[i++] = s; for (; i < 4; ++i) t.shape[i] = 1;
+    n->tensors.push_back(t);
+  };
+  auto add_bn_tr = [&](const ConvLayer& c) {
+    add(std::string(c.name) + ".gamma", n->gamma_off + c.bn, {c.bnC}, 1);
+    add(std::string(c.name) + ".beta", n->beta_off + c.bn, {c.bnC}, 1);
+  };
+  for (int i = 0; i < 3; ++i) {
+    const ConvLayer& c = n->conv[i];
+    add(std::string(c.name) + ".kernel", c.w, {3, 3, c.Cin, c.Cout}, 1);
+    add(std::string(c.name) + ".bias", c.b, {c.Cout}, 1);
+    add_bn_tr(c);
+  }
+  add("enc.dense.kernel", n->dense.w, {6400, n->H1}, 1);
+  add("enc.dense.bias", n->dense.b, {n->H1}, 1);
+  if (variant == VEEX_VARIANT_VAE) {
+    add("enc.z_mean.kernel", n->wh, {100, L}, 1, 1);
+    add("enc.z_mean.bias", n->bh, {L}, 1, 1);
+    add("enc.z_log_var.kernel", n->wh, {100, L}, 1, 2);
+    add("enc.z_log_var.bias", n->bh, {L}, 1, 2);
+  }
+  add("dec.dense.kernel", n->ddense.w, {L, 4096}, 1);
+  add("dec.dense.bias", n->ddense.b, {4096}, 1);
+  add_bn_tr(n->ddense);
+  for (int i = 0; i < 6; ++i) {
+    const ConvLayer& c = n->dc[i];
+    add(std::string(c.name) + ".kernel", c.w, {c.k, c.k, c.Cout, c.Cin}, 1);
+    add(std::string(c.name) + ".bias", c.b, {c.Cout}, 1);
+    if (c.bn >= 0) add_bn_tr(c);
+  }
+  auto add_bn_st = [&](const ConvLayer& c) {
+    add(std::string(c.name) + ".mean", c.bn, {c.bnC}, 0);
+    add(std::string(c.name) + ".var", (long long)n->n_bn + c.bn, {c.bnC}, 0);
+  };
+  for (int i = 0; i < 3; ++i) add_bn_st(n->conv[i]);
+  add_bn_st(n->ddense);
+  for (int i = 0; i < 5; ++i) add_bn_st(n->dc[i]);
+  return n;
+}
+
+extern "C" void veex_net_destroy(VeexNet* n) { delete n; }
+extern "C" long long veex_net_param_floats(const VeexNet* n) { return n ? n->n_params : -1; }
+extern "C" long long veex_net_state_floats(const VeexNet* n) { return n ? n->n_state : -1; }
+extern "C" int veex_net_num_tensors(const VeexNet* n) { return n ? (int)n->tensors.size() : -1; }
+extern "C" int veex_net_tensor_info(const VeexNet* n, int i, char* name, int cap, long long* offset, int* ndim,
+                                    long long* shape4, int* trainable, int* part) {
+  if (n == nullptr || i < 0 || i >= (int)n->tensors.size()) { veex_set_error("tensor_info: bad index"); return VEEX_EINVAL; }
+  const TensorInfo& t = n->tensors[i];
+  if (name != nullptr && cap > 0) { strncpy(name, t.name.c_str(), cap - 1); name[cap - 1] = 0; }
+  if (offset) *offset = t.offset;
+  if (ndim) *ndim = t.ndim;
+  if (shape4) for (int k = 0; k < 4; ++k) shape4[k] = t.shape[k];
+  if (trainable) *trainable = t.trainable;
+  if (part) *part = t.part;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// workspace layout
+// ------------------------------------------------------------------------------------------
+struct WsEntry { std::string name; long long off, n; };
+
+struct Ws {
+  std::vector<WsEntry> e;
+  long long total = 0;
+  long long add(const std::string& name, long long n) {
+    WsEntry x; x.name = name; x.off = total; x.n = n;
+    e.push_back(x);
+    total = align64(total + n);
+    return x.off;
+  }
+  long long get(const char* name, long long* n = nullptr) const {
+    for (const auto& x : e) if (x.name == name) { if (n) *n = x.n; return x.off; }
+    return -1;
+  }
+};
+
+struct SplitPlan { int nsplit; int per; };  // per = rows_per_split (wgrad) or unused
+
+static SplitPlan wgrad_split(const WGParams& pin) {
+  int bm, bn;
+  const int tiles = veex_wg_tiles(pin, &bm, &bn);
+  const int chunks = (pin.R + VEEX_BK - 1) / VEEX_BK;
+  int ns = (768 + tiles - 1) / tiles;
+  const int maxs = (chunks / 4 > 0) ? chunks / 4 : 1;
+  if (ns > maxs) ns = maxs;
+  if (ns < 1) ns = 1;
+  const int cps = (chunks + ns - 1) / ns;
+  SplitPlan s; s.per = cps * VEEX_BK; s.nsplit = (pin.R + s.per - 1) / s.per;
+  return s;
+}
+
+static int gg_split(int mtiles, int Cout, int chunks) {
+  const int ntiles = (Cout + 63) / 64;
+  const int tiles = mtiles * ntiles;
+  int ns = (512 + tiles - 1) / tiles;
+  const int maxs = (chunks / 4 > 0) ? chunks / 4 : 1;
+  if (ns > maxs) ns = maxs;
+  if (ns < 1) ns = 1;
+  const int cps = (chunks + ns - 1) / ns;
+  return (chunks + cps - 1) / cps;
+}
+
+struct Plan {
+  Ws ws;
+  long long bn_scale, bn_shift, bn_rstd;
+  long long act_conv[3], act_h, mulv, eps, z;
+  long long act_dd, act_dc[5], dlogit, rec_b, kl_b, dlsum_b;
+  long long d_conv[3], d_h, dmulv, dz, d_dd, g_dd, d_dc[5];
+  long long slab, partials, losses_tmp;
+  long long slab_n, partials_n;
+};
+
+static long long act_floats(const ConvLayer& c, int B) { return (long long)B * c.Hout * c.Hout * c.Cout; }
+
+// descriptors shared by planning (sizes) and execution
+static void wg_desc_deconv(const VeexNet* n, int i, int B, WGParams& p) {
+  const ConvLayer& c = n->dc[i];
+  memset(&p, 0, sizeof(p));
+  p.Nb = B; p.Hb = c.Hout; p.Wb = c.Hout; p.Cb = c.Cout; p.Hs = c.Hin; p.Ws = c.Hin; p.Cs = c.Cin;
+  p.kh = c.k; p.kw = c.k; p.stride = c.stride; p.pb = c.pb;
+  p.R = B * c.Hin * c.Hin; p.M = c.k * c.k * c.Cout;
+}
+static void wg_desc_conv(const ConvLayer& c, int B, WGParams& p) {
+  memset(&p, 0, sizeof(p));
+  p.Nb = B; p.Hb = c.Hin; p.Wb = c.Hin; p.Cb = c.Cin; p.Hs = c.Hout; p.Ws = c.Hout; p.Cs = c.Cout;
+  p.kh = c.k; p.kw = c.k; p.stride = c.stride; p.pb = c.pb;
+  p.R = B * c.Hout * c.Hout; p.M = c.k * c.k * c.Cin;
+}
+
+static long long gg_tiles_for(int B, int Hout, int Cout, int mode, int stride, int pb) {
+  GGParams p; memset(&p, 0, sizeof(p));
+  p.Nb = B; p.Hout = Hout; p.Wout = Hout; p.Cout = Cout; p.mode = mode; p.stride = stride; p.pb = pb;
+  return veex_gg_m_tiles(p);
+}
+
+static void make_plan(const VeexNet* n, int B, Plan& P) {
+  Ws& w = P.ws;
+  const int L = n->L, H1 = n->H1;
+  P.bn_scale = w.add("bn.scale", n->n_bn);
+  P.bn_shift = w.add("bn.shift", n->n_bn);
+  P.bn_rstd = w.add("bn.rstd", n->n_bn);
+  for (int i = 0; i < 3; ++i) P.act_conv[i] = w.add(std::string("act.") + n->conv[i].name, act_floats(n->conv[i], B));
+  P.act_h = w.add("act.enc.dense", (long long)B * H1);
+  if (n->variant == VEEX_VARIANT_VAE) {
+    P.mulv = w.add("mulv", (long long)B * 2 * L);
+    P.eps = w.add("eps", (long long)B * L);
+    P.z = w.add("z", (long long)B * L);
+  } else {
+    P.mulv = P.eps = -1;
+    P.z = P.act_h;
+  }
+  P.act_dd = w.add("act.dec.dense", (long long)B * 4096);
+  for (int i = 0; i < 5; ++i) P.act_dc[i] = w.add(std::string("act.") + n->dc[i].name, act_floats(n->dc[i], B));
+  P.dlogit = w.add("dlogit", (long long)B * 1600);
+  P.rec_b = w.add("rec_b", B);
+  P.kl_b = w.add("kl_b", B);
+  P.dlsum_b = w.add("dlsum_b", B);
+  P.losses_tmp = w.add("losses_tmp", 4);
+  for (int i = 0; i < 3; ++i) P.d_conv[i] = w.add(std::string("dpre.") + n->conv[i].name, act_floats(n->conv[i], B));
+  P.d_h = w.add("dpre.enc.dense", (long long)B * H1);
+  if (n->variant == VEEX_VARIANT_VAE) P.dmulv = w.add("dmulv", (long long)B * 2 * L); else P.dmulv = -1;
+  P.dz = w.add("dz", (long long)B * L);
+  P.g_dd = w.add("g.dec.dense", (long long)B * 4096);
+  P.d_dd = w.add("dpre.dec.dense", (long long)B * 4096);
+  for (int i = 0; i < 5; ++i) P.d_dc[i] = w.add(std::string("dpre.") + n->dc[i].name, act_floats(n->dc[i], B));
+
+  // scratch sizes: slabs (split-K / wgrad / conv1 / deconv6) and column partials
+  long long slab = 0, part = 0;
+  auto upd = [](long long& m, long long v) { if (v > m) m = v; };
+  WGParams wp;
+  for (int i = 0; i < 5; ++i) { wg_desc_deconv(n, i, B, wp); upd(slab, (long long)wgrad_split(wp).nsplit * wp.M * wp.Cs); }
+  for (int i = 1; i < 3; ++i) { wg_desc_conv(n->conv[i], B, wp); upd(slab, (long long)wgrad_split(wp).nsplit * wp.M * wp.Cs); }
+  wg_desc_conv(n->dense, B, wp); upd(slab, (long long)wgrad_split(wp).nsplit * wp.M * wp.Cs);
+  wg_desc_conv(n->ddense, B, wp); upd(slab, (long long)wgrad_split(wp).nsplit * wp.M * wp.Cs);
+  if (n->variant == VEEX_VARIANT_VAE) {
+    memset(&wp, 0, sizeof(wp));
+    wp.Nb = B; wp.Hb = wp.Wb = wp.Hs = wp.Ws = 1; wp.Cb = 100; wp.Cs = 2 * L; wp.kh = wp.kw = 1; wp.stride = 1;
+    wp.R = B; wp.M = 100;
+    upd(slab, (long long)wgrad_split(wp).nsplit * wp.M * wp.Cs);
+  }
+  upd(slab, (long long)veex_conv1_wgrad_blocks(B) * 576);
+  upd(slab, (long long)B * 448);
+  {  // enc dense forward split-K and dz split-K
+    const int mt = (int)gg_tiles_for(B, 1, H1, 0, 1, 0);
+    upd(slab, (long long)gg_split(mt, H1, 25 * 16) * B * H1);
+    const int mt2 = (int)gg_tiles_for(B, 1, L, 1, 1, 0);
+    upd(slab, (long long)gg_split(mt2, L, 4096 / VEEX_BK) * B * L);
+  }
+  // partials: EPI_BWD launches (m_tiles * 3 * Cout) and row-chunk launches
+  for (int i = 1; i < 5; ++i)  // dgrad of deconv i+1 produces gradient of deconv i's output
+    upd(part, gg_tiles_for(B, n->dc[i - 1].Hout, n->dc[i - 1].Cout, 0, 1, 0) * 3 * n->dc[i - 1].Cout);
+  upd(part, gg_tiles_for(B, 1, 6400, 1, 1, 0) * 3 * 6400);
+  upd(part, gg_tiles_for(B, 10, 128, 1, 2, 0) * 3 * 128);
+  upd(part, gg_tiles_for(B, 20, 64, 1, 2, 0) * 3 * 64);
+  upd(part, gg_tiles_for(B, 1, H1, 1, 1, 0) * 3 * H1);
+  upd(part, (long long)veex_bnrelu_bwd_rows_chunks(B) * 3 * 4096);
+  P.slab_n = slab; P.partials_n = part;
+  P.slab = w.add("scratch.slab", slab);
+  P.partials = w.add("scratch.partials", part);
+}
+
+extern "C" long long veex_net_workspace_floats(const VeexNet* n, int B) {
+  if (n == nullptr || B < 1) { veex_set_error("workspace_floats: bad arguments"); return -1; }
+  Plan P; make_plan(n, B, P);
+  return P.ws.total;
+}
+
+extern "C" long long veex_net_ws_offset(const VeexNet* n, int B, const char* name, long long* nfloats) {
+  if (n == nullptr || B < 1 || name == nullptr) return -1;
+  Plan P; make_plan(n, B, P);
+  return P.ws.get(name, nfloats);
+}
+
+// ------------------------------------------------------------------------------------------
+// execution helpers
+// ------------------------------------------------------------------------------------------
+struct Ctx {
+  const VeexNet* n;
+  const float* P;     // params
+  const float* S;     // state (mean | var)
+  float* ws;
+  Plan plan;
+  int B;
+  hipStream_t st;
+  const float* scale(int bn) const { return ws + plan.bn_scale + bn; }
+  const float* shift(int bn) const { return ws + plan.bn_shift + bn; }
+  const float* rstd(int bn) const { return ws + plan.bn_rstd + bn; }
+  const float* mean(int bn) const { return S + bn; }
+};
+
+static int check_common(const VeexNet* n, const void* params, const void* state, int B, const float* ws,
+                        long long ws_floats) {
+  if (n == nullptr || params == nullptr || state == nullptr || ws == nullptr) { veex_set_error("null argument"); return VEEX_EINVAL; }
+  if (B < 1 || B > (1 << 20)) { veex_set_error("bad batch %d", B); return VEEX_EINVAL; }
+  const long long need = veex_net_workspace_floats(n, B);
+  if (ws_floats < need) { veex_set_error("workspace too small: %lld floats given, %lld needed", ws_floats, need); return VEEX_ENOMEM; }
+  return 0;
+}
+
+static int run_bn_prepare(Ctx& c) {
+  const VeexNet* n = c.n;
+  return veex_bn_prepare(c.P + n->gamma_off, c.P + n->beta_off, c.S, c.S + n->n_bn, c.ws + c.plan.bn_scale,
+                         c.ws + c.plan.bn_shift, c.ws + c.plan.bn_rstd, n->n_bn, BN_EPS, c.st);
+}
+
+// forward GEMM layer: in (with producer BN) -> out = relu?(conv + bias)
+static int fwd_gemm(Ctx& c, const ConvLayer& l, int mode, const float* in, int in_bn, int in_bnC, int aff_spatial,
+                    float* out, int relu) {
+  GGParams p; memset(&p, 0, sizeof(p));
+  p.A = in; p.W = c.P + l.w; p.Out = out; p.bias = c.P + l.b;
+  if (in_bn >= 0) { p.a_scale = c.scale(in_bn); p.a_shift = c.shift(in_bn); p.aff_mask = in_bnC - 1; p.aff_spatial = aff_spatial; }
+  p.Nb = c.B; p.Hin = l.Hin; p.Win = l.Hin; p.Cin = l.Cin; p.Hout = l.Hout; p.Wout = l.Hout; p.Cout = l.Cout;
+  p.kh = l.k; p.kw = l.k; p.stride = l.stride; p.pb = l.pb; p.mode = mode;
+  p.epi = VEEX_EPI_FWD; p.relu = relu; p.nsplit = 1;
+  return veex_launch_gather_gemm(p, c.st);
+}
+
+static int encoder_forward(Ctx& c, const float* x) {
+  const VeexNet* n = c.n;
+  const Plan& P = c.plan;
+  float* ws = c.ws;
+  TRY(veex_conv1_fwd(x, c.P + n->conv[0].w, c.P + n->conv[0].b, ws + P.act_conv[0], c.B, c.st));
+  TRY(fwd_gemm(c, n->conv[1], 0, ws + P.act_conv[0], n->conv[0].bn, 64, 0, ws + P.act_conv[1], 1));
+  TRY(fwd_gemm(c, n->conv[2], 0, ws + P.act_conv[1], n->conv[1].bn, 128, 0, ws + P.act_conv[2], 1));
+  {  // Dense(6400 -> H1, relu) as a 5x5 VALID conv, split-K over taps/channels
+    const ConvLayer& l = n->dense;
+    GGParams p; memset(&p, 0, sizeof(p));
+    p.A = ws + P.act_conv[2]; p.W = c.P + l.w; p.Out = ws + P.slab;
+    p.a_scale = c.scale(n->conv[2].bn); p.a_shift = c.shift(n->conv[2].bn); p.aff_mask = 255;
+    p.Nb = c.B; p.Hin = 5; p.Win = 5; p.Cin = 256; p.Hout = 1; p.Wout = 1; p.Cout = l.Cout;
+    p.kh = 5; p.kw = 5; p.stride = 1; p.pb = 0; p.mode = 0; p.epi = VEEX_EPI_RAW;
+    const int chunks = 25 * 16;
+    GGParams q = p;
+    const int mt = veex_gg_m_tiles(q);
+    p.nsplit = gg_split(mt, l.Cout, chunks);
+    p.chunks_per_split = (chunks + p.nsplit - 1) / p.nsplit;
+    p.slab_stride = (long long)c.B * l.Cout;
+    TRY(veex_launch_gather_gemm(p, c.st));
+    TRY(veex_slab_sum(ws + P.slab, p.nsplit, p.slab_stride, p.slab_stride, ws + P.act_h, c.P + l.b, l.Cout, 1, c.st));
+  }
+  if (n->variant == VEEX_VARIANT_VAE) {  // both heads as one [100][2L] GEMM (models.py:240-241)
+    GGParams p; memset(&p, 0, sizeof(p));
+    p.A = ws + P.act_h; p.W = c.P + n->wh; p.Out = ws + P.mulv; p.bias = c.P + n->bh;
+    p.Nb = c.B; p.Hin = p.Win = p.Hout = p.Wout = 1; p.Cin = 100; p.Cout = 2 * n->L;
+    p.kh = p.kw = 1; p.stride = 1; p.mode = 0; p.epi = VEEX_EPI_FWD; p.relu = 0; p.nsplit = 1;
+    TRY(veex_launch_gather_gemm(p, c.st));
+  }
+  return 0;
+}
+
+// decoder up to deconv5's activation
+static int decoder_trunk(Ctx& c, const float* z) {
+  const VeexNet* n = c.n;
+  const Plan& P = c.plan;
+  float* ws = c.ws;
+  TRY(fwd_gemm(c, n->ddense, 0, z, -1, 0, 0, ws + P.act_dd, 1));
+  const float* in = ws + P.act_dd;
+  int in_bn = n->ddense.bn, in_bnC = 4096, spatial = 1;
+  for (int i = 0; i < 5; ++i) {
+    TRY(fwd_gemm(c, n->dc[i], 1, in, in_bn, in_bnC, spatial, ws + P.act_dc[i], 1));
+    in = ws + P.act_dc[i]; in_bn = n->dc[i].bn; in_bnC = n->dc[i].Cout; spatial = 0;
+  }
+  return 0;
+}
+
+static int deconv6_forward(Ctx& c, const float* target, float* logits, float* recon, float* dlogit, float* rec_b,
+                           float* dlsum_b) {
+  const VeexNet* n = c.n;
+  return veex_deconv6_bce_fwd(c.ws + c.plan.act_dc[4], c.scale(n->dc[4].bn), c.shift(n->dc[4].bn), c.P + n->dc[5].w,
+                              c.P + n->dc[5].b, target, logits, recon, dlogit, rec_b, dlsum_b, c.B, 1.0f / c.B, c.st);
+}
+
+static int run_wgrad(Ctx& c, WGParams& p, float* dW) {
+  const SplitPlan s = wgrad_split(p);
+  p.nsplit = s.nsplit; p.rows_per_split = s.per;
+  const long long n = (long long)p.M * p.Cs;
+  if (s.nsplit == 1) { p.Out = dW; return veex_launch_wgrad(p, c.st); }
+  if ((long long)s.nsplit * n > c.plan.slab_n) { veex_set_error("internal: slab scratch too small"); return VEEX_ENOMEM; }
+  p.Out = c.ws + c.plan.slab;
+  TRY(veex_launch_wgrad(p, c.st));
+  return veex_slab_sum(c.ws + c.plan.slab, s.nsplit, n, n, dW, nullptr, 1, 0, c.st);
+}
+
+// dgrad GEMM with BN/ReLU-backward epilogue + finalisation of the producing layer's bias/gamma/beta grads
+static int dgrad_bwd(Ctx& c, GGParams& p, const ConvLayer& prod, const float* aux, float* dpre, float* G, int want_param_grads) {
+  const VeexNet* n = c.n;
+  p.Out = dpre; p.aux = aux; p.epi = VEEX_EPI_BWD; p.relu = 1; p.nsplit = 1;
+  if (prod.bn >= 0) { p.e_scale = c.scale(prod.bn); p.epi_cmask = prod.bnC - 1; }
+  p.partials = want_param_grads ? c.ws + c.plan.partials : nullptr;
+  GGParams q = p;
+  const int mt = veex_gg_m_tiles(q);
+  if (want_param_grads && (long long)mt * 3 * p.Cout > c.plan.partials_n) { veex_set_error("internal: partials scratch too small"); return VEEX_ENOMEM; }
+  TRY(veex_launch_gather_gemm(p, c.st));
+  if (!want_param_grads) return 0;
+  const int nch = (prod.bn >= 0) ? prod.bnC : p.Cout;
+  return veex_colsum_finalize(c.ws + c.plan.partials, mt, 3LL * p.Cout, p.Cout, nch,
+                              prod.bn >= 0 ? c.scale(prod.bn) : nullptr, prod.bn >= 0 ? c.mean(prod.bn) : nullptr,
+                              prod.bn >= 0 ? c.rstd(prod.bn) : nullptr, G + prod.b,
+                              prod.bn >= 0 ? G + n->gamma_off + prod.bn : nullptr,
+                              prod.bn >= 0 ? G + n->beta_off + prod.bn : nullptr, c.st);
+}
+
+// encoder backward from d(pre-activation of enc.dense) in ws+d_h down to d(pre-act conv1) in ws+d_conv[0]
+static int encoder_backward(Ctx& c, const float* x, float* G, int want_param_grads) {
+  const VeexNet* n = c.n;
+  const Plan& P = c.plan;
+  float* ws = c.ws;
+  const int H1 = n->H1;
+  if (want_param_grads) {  // dW of enc.dense: big = BN3(a3) (5,5,256), small = d_h
+    WGParams w; wg_desc_conv(n->dense, c.B, w);
+    w.Big = ws + P.act_conv[2]; w.Small = ws + P.d_h;
+    w.b_scale = c.scale(n->conv[2].bn); w.b_shift = c.shift(n->conv[2].bn); w.b_aff_mask = 255;
+    TRY(run_wgrad(c, w, G + n->dense.w));
+  }
+  {  // g3 = d_h . W^T as a plain GEMM over the flattened (h,w,c) vector; epilogue = BN3/ReLU backward
+    GGParams p; memset(&p, 0, sizeof(p));
+    p.A = ws + P.d_h; p.W = c.P + n->dense.w;
+    p.Nb = c.B; p.Hin = p.Win = p.Hout = p.Wout = 1; p.Cin = H1; p.Cout = 6400;
+    p.kh = p.kw = 1; p.stride = 1; p.mode = 1;
+    TRY(dgrad_bwd(c, p, n->conv[2], ws + P.act_conv[2], ws + P.d_conv[2], G, want_param_grads));
+  }
+  for (int i = 2; i >= 1; --i) {
+    const ConvLayer& l = n->conv[i];
+    if (want_param_grads) {
+      WGParams w; wg_desc_conv(l, c.B, w);
+      w.Big = ws + P.act_conv[i - 1]; w.Small = ws + P.d_conv[i];
+      w.b_scale = c.scale(n->conv[i - 1].bn); w.b_shift = c.shift(n->conv[i - 1].bn); w.b_aff_mask = n->conv[i - 1].Cout - 1;
+      TRY(run_wgrad(c, w, G + l.w));
+    }
+    GGParams p; memset(&p, 0, sizeof(p));
+    p.A = ws + P.d_conv[i]; p.W = c.P + l.w;
+    p.Nb = c.B; p.Hin = p.Win = l.Hout; p.Cin = l.Cout; p.Hout = p.Wout = l.Hin; p.Cout = l.Cin;
+    p.kh = p.kw = 3; p.stride = 2; p.pb = l.pb; p.mode = 1;
+    TRY(dgrad_bwd(c, p, n->conv[i - 1], ws + P.act_conv[i - 1], ws + P.d_conv[i - 1], G, want_param_grads));
+  }
+  if (want_param_grads) {
+    const int nb = veex_conv1_wgrad_blocks(c.B);
+    TRY(veex_conv1_wgrad(x, ws + P.d_conv[0], ws + P.slab, c.B, c.st));
+    TRY(veex_slab_sum(ws + P.slab, nb, 576, 576, G + n->conv[0].w, nullptr, 1, 0, c.st));
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// public network entry points
+// ------------------------------------------------------------------------------------------
+static int encode_impl(Ctx& c, const float* x, float* eps_io, int flags, unsigned long long seed,
+                       unsigned long long first_sample, int want_kl) {
+  const VeexNet* n = c.n;
+  const Plan& P = c.plan;
+  TRY(encoder_forward(c, x));
+  if (n->variant == VEEX_VARIANT_VAE) {
+    const int philox = (flags & VEEX_F_PHILOX) ? 1 : 0;
+    float* eps = c.ws + P.eps;
+    if (!philox) {
+      if (eps_io == nullptr) { veex_set_error("epsilon buffer required unless VEEX_F_PHILOX is set"); return VEEX_EINVAL; }
+      if (hipMemcpyAsync(eps, eps_io, sizeof(float) * (size_t)c.B * n->L, hipMemcpyDeviceToDevice, c.st) != hipSuccess) {
+        veex_set_error("epsilon copy failed"); return VEEX_ELAUNCH;
+      }
+    }
+    TRY(veex_reparam_kl_fwd(c.ws + P.mulv, eps, c.ws + P.z, want_kl ? c.ws + P.kl_b : nullptr, c.B, n->L, philox, seed,
+                            first_sample, c.st));
+    if (philox && eps_io != nullptr) {
+      if (hipMemcpyAsync(eps_io, eps, sizeof(float) * (size_t)c.B * n->L, hipMemcpyDeviceToDevice, c.st) != hipSuccess) {
+        veex_set_error("epsilon copy failed"); return VEEX_ELAUNCH;
+      }
+    }
+  }
+  return 0;
+}
+
+extern "C" int veex_net_encode(const VeexNet* n, const float* params, const float* state, const float* x, float* eps_io,
+                               int B, int flags, unsigned long long seed, unsigned long long first_sample, float* ws,
+                               long long ws_floats, float* z_mean, float* z_log_var, float* z, veexStream_t st) {
+  TRY(check_common(n, params, state, B, ws, ws_floats));
+  if (x == nullptr) { veex_set_error("null input"); return VEEX_EINVAL; }
+  Ctx c; c.n = n; c.P = params; c.S = state; c.ws = ws; c.B = B; c.st = st;
+  make_plan(n, B, c.plan);
+  TRY(run_bn_prepare(c));
+  TRY(encode_impl(c, x, eps_io, flags, seed, first_sample, 0));
+  const int L = n->L;
+  if (n->variant == VEEX_VARIANT_VAE) {
+    // split [B][2L] into the two heads with strided 2-D copies
+    if (z_mean != nullptr &&
+        hipMemcpy2DAsync(z_mean, sizeof(float) * L, ws + c.plan.mulv, sizeof(float) * 2 * L, sizeof(float) * L, B,
+                         hipMemcpyDeviceToDevice, st) != hipSuccess) { veex_set_error("copy failed"); return VEEX_ELAUNCH; }
+    if (z_log_var != nullptr &&
+        hipMemcpy2DAsync(z_log_var, sizeof(float) * L, ws + c.plan.mulv + L, sizeof(float) * 2 * L, sizeof(float) * L, B,
+                         hipMemcpyDeviceToDevice, st) != hipSuccess) { veex_set_error("copy failed"); return VEEX_ELAUNCH; }
+  }
+  if (z != nullptr &&
+      hipMemcpyAsync(z, ws + c.plan.z, sizeof(float) * (size_t)B * L, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+    veex_set_error("copy failed"); return VEEX_ELAUNCH;
+  }
+  return 0;
+}
+
+extern "C" int veex_net_decode(const VeexNet* n, const float* params, const float* state, const float* z, int B,
+                               float* ws, long long ws_floats, float* recon, float* logits, veexStream_t st) {
+  TRY(check_common(n, params, state, B, ws, ws_floats));
+  if (z == nullptr) { veex_set_error("null input"); return VEEX_EINVAL; }
+  Ctx c; c.n = n; c.P = params; c.S = state; c.ws = ws; c.B = B; c.st = st;
+  make_plan(n, B, c.plan);
+  TRY(run_bn_prepare(c));
+  TRY(decoder_trunk(c, z));
+  return deconv6_forward(c, nullptr, logits, recon, nullptr, nullptr, nullptr);
+}
+
+extern "C" int veex_net_forward(const VeexNet* n, const float* params, const float* state, const float* x, float* eps_io,
+                                int B, int flags, unsigned long long seed, unsigned long long first_sample, float* ws,
+                                long long ws_floats, float* recon, float* losses, float* metrics, veexStream_t st) {
+  TRY(check_common(n, params, state, B, ws, ws_floats));
+  if (x == nullptr) { veex_set_error("null input"); return VEEX_EINVAL; }
+  Ctx c; c.n = n; c.P = params; c.S = state; c.ws = ws; c.B = B; c.st = st;
+  make_plan(n, B, c.plan);
+  const Plan& P = c.plan;
+  TRY(run_bn_prepare(c));
+  TRY(encode_impl(c, x, eps_io, flags, seed, first_sample, 1));
+  const float* zdec = ws + P.z;
+  if ((flags & VEEX_F_ZMEAN_DECODE) && n->variant == VEEX_VARIANT_VAE) {
+    if (hipMemcpy2DAsync(ws + P.dz, sizeof(float) * n->L, ws + P.mulv, sizeof(float) * 2 * n->L, sizeof(float) * n->L, B,
+                         hipMemcpyDeviceToDevice, st) != hipSuccess) { veex_set_error("copy failed"); return VEEX_ELAUNCH; }
+    zdec = ws + P.dz;
+  }
+  TRY(decoder_trunk(c, zdec));
+  TRY(deconv6_forward(c, x, nullptr, recon, nullptr, ws + P.rec_b, nullptr));
+  return veexi_loss_finalize(ws + P.rec_b, n->variant == VEEX_VARIANT_VAE ? ws + P.kl_b : nullptr, nullptr, B, losses,
+                             metrics, nullptr, st);
+}
+
+extern "C" int veex_net_train_fwd_bwd(const VeexNet* n, const float* params, const float* state, const float* x,
+                                      float* eps_io, int B, int flags, unsigned long long seed,
+                                      unsigned long long first_sample, float* ws, long long ws_floats, float* G,
+                                      float* losses, float* metrics, veexStream_t st) {
+  TRY(check_common(n, params, state, B, ws, ws_floats));
+  if (x == nullptr || G == nullptr) { veex_set_error("null input"); return VEEX_EINVAL; }
+  Ctx c; c.n = n; c.P = params; c.S = state; c.ws = ws; c.B = B; c.st = st;
+  make_plan(n, B, c.plan);
+  const Plan& P = c.plan;
+  const int L = n->L, H1 = n->H1;
+  const bool vae = (n->variant == VEEX_VARIANT_VAE);
+
+  // ---- forward (models.py:152-163) ----
+  TRY(run_bn_prepare(c));
+  TRY(encode_impl(c, x, eps_io, flags, seed, first_sample, 1));
+  TRY(decoder_trunk(c, ws + P.z));
+  TRY(deconv6_forward(c, x, nullptr, nullptr, ws + P.dlogit, ws + P.rec_b, ws + P.dlsum_b));
+  TRY(veexi_loss_finalize(ws + P.rec_b, vae ? ws + P.kl_b : nullptr, ws + P.dlsum_b, B, losses, metrics,
+                          G + n->dc[5].b, st));
+
+  // ---- backward (tape.gradient, models.py:166) ----
+  {  // deconv6 + BN5/ReLU backward
+    const ConvLayer& l5 = n->dc[4];
+    TRY(veex_deconv6_bwd(ws + P.dlogit, ws + P.act_dc[4], c.scale(l5.bn), c.shift(l5.bn), c.P + n->dc[5].w,
+                         ws + P.d_dc[4], ws + P.slab, B, st));
+    TRY(veex_slab_sum(ws + P.slab, B, 448, 256, G + n->dc[5].w, nullptr, 1, 0, st));
+    TRY(veex_colsum_finalize(ws + P.slab + 256, B, 448, 64, 64, c.scale(l5.bn), c.mean(l5.bn), c.rstd(l5.bn), G + l5.b,
+                             G + n->gamma_off + l5.bn, G + n->beta_off + l5.bn, st));
+  }
+  for (int i = 4; i >= 0; --i) {
+    const ConvLayer& l = n->dc[i];
+    const float* in = (i == 0) ? ws + P.act_dd : ws + P.act_dc[i - 1];
+    const ConvLayer& prod = (i == 0) ? n->ddense : n->dc[i - 1];
+    {  // dW: big = d(pre-act) of this layer, small = its input (with the producer's BN)
+      WGParams w; wg_desc_deconv(n, i, B, w);
+      w.Big = ws + P.d_dc[i]; w.Small = in;
+      w.s_scale = c.scale(prod.bn); w.s_shift = c.shift(prod.bn); w.s_aff_mask = prod.bnC - 1; w.s_aff_spatial = (i == 0);
+      TRY(run_wgrad(c, w, G + l.w));
+    }
+    GGParams p; memset(&p, 0, sizeof(p));
+    p.A = ws + P.d_dc[i]; p.W = c.P + l.w;
+    p.Nb = B; p.Hin = p.Win = l.Hout; p.Cin = l.Cout; p.Hout = p.Wout = l.Hin; p.Cout = l.Cin;
+    p.kh = p.kw = l.k; p.stride = l.stride; p.pb = l.pb; p.mode = 0;
+    if (i > 0) {
+      TRY(dgrad_bwd(c, p, prod, ws + P.act_dc[i - 1], ws + P.d_dc[i - 1], G, 1));
+    } else {
+      // BatchNorm of dec.dense runs over the flattened 4096 features: plain dgrad, then row-wise BN/ReLU backward
+      p.Out = ws + P.g_dd; p.epi = VEEX_EPI_FWD; p.relu = 0; p.bias = nullptr; p.nsplit = 1;
+      TRY(veex_launch_gather_gemm(p, st));
+      const int chunks = veex_bnrelu_bwd_rows_chunks(B);
+      TRY(veex_bnrelu_bwd_rows(ws + P.g_dd, ws + P.act_dd, c.scale(prod.bn), ws + P.d_dd, ws + P.partials, B, 4096, 4096, st));
+      TRY(veex_colsum_finalize(ws + P.partials, chunks, 3LL * 4096, 4096, 4096, c.scale(prod.bn), c.mean(prod.bn),
+                               c.rstd(prod.bn), G + prod.b, G + n->gamma_off + prod.bn, G + n->beta_off + prod.bn, st));
+    }
+  }
+  {  // dec.dense: dW = z^T . dpre ; dz = dpre . W^T (split-K)
+    WGParams w; wg_desc_conv(n->ddense, B, w);
+    w.Big = ws + P.z; w.Small = ws + P.d_dd;
+    TRY(run_wgrad(c, w, G + n->ddense.w));
+    GGParams p; memset(&p, 0, sizeof(p));
+    p.A = ws + P.d_dd; p.W = c.P + n->ddense.w; p.Out = ws + P.slab;
+    p.Nb = B; p.Hin = p.Win = p.Hout = p.Wout = 1; p.Cin = 4096; p.Cout = L;
+    p.kh = p.kw = 1; p.stride = 1; p.mode = 1; p.epi = VEEX_EPI_RAW;
+    GGParams q = p;
+    const int mt = veex_gg_m_tiles(q);
+    const int chunks = 4096 / VEEX_BK;
+    p.nsplit = gg_split(mt, L, chunks);
+    p.chunks_per_split = (chunks + p.nsplit - 1) / p.nsplit;
+    p.slab_stride = (long long)B * L;
+    TRY(veex_launch_gather_gemm(p, st));
+    TRY(veex_slab_sum(ws + P.slab, p.nsplit, p.slab_stride, p.slab_stride, ws + P.dz, nullptr, 1, 0, st));
+  }
+  if (vae) {
+    TRY(veex_reparam_kl_bwd(ws + P.dz, ws + P.mulv, ws + P.eps, ws + P.dmulv, B, L, 1.0f / B, st));
+    {  // head biases: column sums of dmulv
+      const int chunks = veex_bnrelu_bwd_rows_chunks(B);
+      TRY(veex_bnrelu_bwd_rows(ws + P.dmulv, nullptr, nullptr, nullptr, ws + P.partials, B, 2 * L, 0, st));
+      TRY(veex_colsum_finalize(ws + P.partials, chunks, 3LL * 2 * L, 2 * L, 2 * L, nullptr, nullptr, nullptr, G + n->bh,
+                               nullptr, nullptr, st));
+    }
+    {  // dWh = h^T . dmulv
+      WGParams w; memset(&w, 0, sizeof(w));
+      w.Big = ws + P.act_h; w.Small = ws + P.dmulv;
+      w.Nb = B; w.Hb = w.Wb = w.Hs = w.Ws = 1; w.Cb = 100; w.Cs = 2 * L; w.kh = w.kw = 1; w.stride = 1;
+      w.R = B; w.M = 100;
+      TRY(run_wgrad(c, w, G + n->wh));
+    }
+    {  // d h = dmulv . Wh^T, ReLU backward of enc.dense, bias gradient of enc.dense
+      GGParams p; memset(&p, 0, sizeof(p));
+      p.A = ws + P.dmulv; p.W = c.P + n->wh;
+      p.Nb = B; p.Hin = p.Win = p.Hout = p.Wout = 1; p.Cin = 2 * L; p.Cout = 100;
+      p.kh = p.kw = 1; p.stride = 1; p.mode = 1;
+      TRY(dgrad_bwd(c, p, n->dense, ws + P.act_h, ws + P.d_h, G, 1));
+    }
+  } else {  // AE: z is the ReLU bottleneck itself (models_standard.py:108)
+    const int chunks = veex_bnrelu_bwd_rows_chunks(B);
+    TRY(veex_bnrelu_bwd_rows(ws + P.dz, ws + P.act_h, nullptr, ws + P.d_h, ws + P.partials, B, H1, 0, st));
+    TRY(veex_colsum_finalize(ws + P.partials, chunks, 3LL * H1, H1, H1, nullptr, nullptr, nullptr, G + n->dense.b,
+                             nullptr, nullptr, st));
+  }
+  TRY(encoder_backward(c, x, G, 1));
+  return 0;
+}
+
+extern "C" int veex_net_attribute(const VeexNet* n, const float* params, const float* state, const float* x, int B,
+                                  const int* units, int n_units, int grad_x_input, float* ws, long long ws_floats,
+                                  float* out, veexStream_t st) {
+  TRY(check_common(n, params, state, B, ws, ws_floats));
+  if (x == nullptr || out == nullptr || units == nullptr || n_units < 1) { veex_set_error("attribute: bad arguments"); return VEEX_EINVAL; }
+  for (int u = 0; u < n_units; ++u)
+    if (units[u] < 0 || units[u] >= n->L) { veex_set_error("attribute: unit %d out of range", units[u]); return VEEX_EINVAL; }
+  Ctx c; c.n = n; c.P = params; c.S = state; c.ws = ws; c.B = B; c.st = st;
+  make_plan(n, B, c.plan);
+  const Plan& P = c.plan;
+  TRY(run_bn_prepare(c));
+  TRY(encoder_forward(c, x));
+  const bool vae = (n->variant == VEEX_VARIANT_VAE);
+  for (int u = 0; u < n_units; ++u) {
+    TRY(veexi_attr_seed(ws + P.act_h, vae ? params + n->wh : nullptr, ws + P.d_h, B, n->H1, 2 * n->L, units[u],
+                        vae ? 0 : 1, st));
+    TRY(encoder_backward(c, x, nullptr, 0));
+    TRY(veex_conv1_dgrad(ws + P.d_conv[0], params + n->conv[0].w, grad_x_input ? x : nullptr,
+                         out + (long long)u * B * 1600, B, st));
+  }
+  return 0;
+}

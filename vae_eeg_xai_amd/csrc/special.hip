@@ -1,0 +1,652 @@
+// HBM-bound kernels of the VAE hot path (everything that is not MFMA work):
+//   conv1 (Cin=1, K=9) forward / weight-grad / input-grad        models.py:219-223
+//   deconv6 (Cout=1) fused with BCE-from-logits + per-sample reduction, and its backward
+//                                                               models.py:300-301,156-160
+//   reparameterisation + analytic KL (Philox or injected epsilon) models.py:10-22,161-162
+//   BatchNorm(inference)/ReLU backward over [rows][cols], column-sum finalisation
+//   split-K / weight-grad slab reduction, TF-form Adam, loss finalisation.
+// All of them stream each operand once with 16-byte accesses and reduce with wavefront
+// shuffles + one LDS pass; cross-block sums go through partial slabs (no float atomics, so
+// results are bitwise reproducible run to run).
+#include "veex_internal.h"
+
+#define IMG 40
+#define C1H 20          // conv1 output 20x20
+#define D5H 39          // deconv5 output 39x39 (deconv6 input)
+#define NCH 64          // channels of conv1 output / deconv6 input
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// conv1: x [B][40][40] -> a1 [B][20][20][64] = relu(conv3x3 s2 SAME(pad 0/1) + bias)
+// thread = (pixel lane, 4 channels); 9x4 weights in registers; one float4 store per pixel.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, float* __restrict__ out,
+                                                        int npix) {
+  const int cq = threadIdx.x & 15, pg = threadIdx.x >> 4;
+  float4 w[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const float4*>(W + t * NCH + 4 * cq);
+  const float4 b4 = *reinterpret_cast<const float4*>(bias + 4 * cq);
+  for (int pix = blockIdx.x * 16 + pg; pix < npix; pix += gridDim.x * 16) {
+    const int n = pix / (C1H * C1H), rem = pix - n * (C1H * C1H);
+    const int oy = rem / C1H, ox = rem - oy * C1H;
+    const float* xs = x + (long long)n * (IMG * IMG);
+    float4 acc = b4;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = 2 * oy + ky;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = 2 * ox + kx;
+        const float v = (iy < IMG && ix < IMG) ? xs[iy * IMG + ix] : 0.f;
+        const float4 ww = w[ky * 3 + kx];
+        acc.x = fmaf(v, ww.x, acc.x); acc.y = fmaf(v, ww.y, acc.y);
+        acc.z = fmaf(v, ww.z, acc.z); acc.w = fmaf(v, ww.w, acc.w);
+      }
+    }
+    acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+    *reinterpret_cast<float4*>(out + (long long)pix * NCH + 4 * cq) = acc;
+  }
+}
+
+// dW1[tap][co] partials: slab[block][9][64]
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dpre,
+                                                          float* __restrict__ slab, int npix) {
+  __shared__ __attribute__((aligned(16))) float red[16 * 9 * NCH];
+  const int cq = threadIdx.x & 15, pg = threadIdx.x >> 4;
+  float4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int pix = blockIdx.x * 16 + pg; pix < npix; pix += gridDim.x * 16) {
+    const int n = pix / (C1H * C1H), rem = pix - n * (C1H * C1H);
+    const int oy = rem / C1H, ox = rem - oy * C1H;
+    const float* xs = x + (long long)n * (IMG * IMG);
+    const float4 g = *reinterpret_cast<const float4*>(dpre + (long long)pix * NCH + 4 * cq);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = 2 * oy + ky;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = 2 * ox + kx;
+        const float v = (iy < IMG && ix < IMG) ? xs[iy * IMG + ix] : 0.f;
+        float4& a = acc[ky * 3 + kx];
+        a.x = fmaf(v, g.x, a.x); a.y = fmaf(v, g.y, a.y); a.z = fmaf(v, g.z, a.z); a.w = fmaf(v, g.w, a.w);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) *reinterpret_cast<float4*>(red + (pg * 9 + t) * NCH + 4 * cq) = acc[t];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 9 * NCH; i += 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int g2 = 0; g2 < 16; ++g2) s += red[g2 * 9 * NCH + i];
+    slab[(long long)blockIdx.x * (9 * NCH) + i] = s;
+  }
+}
+
+// dx[n][iy][ix] = sum_{ky,kx,co} dpre1[n][(iy-ky)/2][(ix-kx)/2][co] * W1[ky][kx][co]  (attribution only)
+// 16 lanes per input pixel, 4 channels per lane.  mul (nullable) = x for gradient*input.
+__global__ __launch_bounds__(256) void conv1_dgrad_kernel(const float* __restrict__ dpre, const float* __restrict__ W,
+                                                          const float* __restrict__ mul, float* __restrict__ dx,
+                                                          int npix) {
+  const int cq = threadIdx.x & 15, pg = threadIdx.x >> 4;
+  float4 w[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const float4*>(W + t * NCH + 4 * cq);
+  const int iters = (npix + gridDim.x * 16 - 1) / (gridDim.x * 16);
+  for (int it = 0; it < iters; ++it) {
+    const int pix = (it * gridDim.x + blockIdx.x) * 16 + pg;
+    float s = 0.f;
+    if (pix < npix) {
+      const int n = pix / (IMG * IMG), rem = pix - n * (IMG * IMG);
+      const int iy = rem / IMG, ix = rem - iy * IMG;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int ty = iy - ky;
+        if (ty < 0 || (ty & 1) || (ty >> 1) >= C1H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int tx = ix - kx;
+          if (tx < 0 || (tx & 1) || (tx >> 1) >= C1H) continue;
+          const float4 g = *reinterpret_cast<const float4*>(
+              dpre + ((long long)(n * C1H + (ty >> 1)) * C1H + (tx >> 1)) * NCH + 4 * cq);
+          const float4 ww = w[ky * 3 + kx];
+          s = fmaf(g.x, ww.x, s); s = fmaf(g.y, ww.y, s); s = fmaf(g.z, ww.z, s); s = fmaf(g.w, ww.w, s);
+        }
+      }
+    }
+    s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
+    if (cq == 0 && pix < npix) dx[pix] = (mul != nullptr) ? s * mul[pix] : s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// deconv6 + sigmoid + BCE-from-logits, one block per sample.
+//   logits[oy][ox] = b + sum_{ky,kx in {0,1}} sum_ci y5[oy-ky][ox-kx][ci] * W6[ky][kx][ci],  y5 = BN5(a5)
+// phase 1: per input pixel the 4 tap dot products (16 lanes x 4 channels, shuffle reduce) -> LDS
+// phase 2: per output pixel gather <=4 of them, BCE, dlogit = (sigmoid - t)/B, block reduction.
+// ---------------------------------------------------------------------------------------
+#define D6_THREADS 512
+__global__ __launch_bounds__(D6_THREADS) void deconv6_bce_fwd_kernel(
+    const float* __restrict__ a5, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ W6, const float* __restrict__ b6, const float* __restrict__ target,
+    float* __restrict__ logits, float* __restrict__ recon, float* __restrict__ dlogit,
+    float* __restrict__ rec_b, float* __restrict__ dlsum_b, float inv_batch) {
+  __shared__ __attribute__((aligned(16))) float d[D5H * D5H * 4];
+  __shared__ float redbuf[2 * (D6_THREADS / 64)];
+  const int n = blockIdx.x;
+  const int cq = threadIdx.x & 15, pg = threadIdx.x >> 4;
+  constexpr int NPG = D6_THREADS / 16;
+  float4 w[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) w[t] = *reinterpret_cast<const float4*>(W6 + t * NCH + 4 * cq);
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (scale != nullptr) {
+    sc = *reinterpret_cast<const float4*>(scale + 4 * cq);
+    sh = *reinterpret_cast<const float4*>(shift + 4 * cq);
+  }
+  const float* src = a5 + (long long)n * (D5H * D5H * NCH);
+  constexpr int NIT = (D5H * D5H + NPG - 1) / NPG;
+  for (int it = 0; it < NIT; ++it) {
+    const int pix = it * NPG + pg;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (pix < D5H * D5H) {
+      float4 a = *reinterpret_cast<const float4*>(src + pix * NCH + 4 * cq);
+      a.x = fmaf(a.x, sc.x, sh.x); a.y = fmaf(a.y, sc.y, sh.y); a.z = fmaf(a.z, sc.z, sh.z); a.w = fmaf(a.w, sc.w, sh.w);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float v = a.x * w[t].x;
+        v = fmaf(a.y, w[t].y, v); v = fmaf(a.z, w[t].z, v); v = fmaf(a.w, w[t].w, v);
+        s[t] = v;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      s[t] += __shfl_xor(s[t], 8); s[t] += __shfl_xor(s[t], 4);
+      s[t] += __shfl_xor(s[t], 2); s[t] += __shfl_xor(s[t], 1);
+    }
+    if (cq == 0 && pix < D5H * D5H) *reinterpret_cast<float4*>(d + pix * 4) = make_float4(s[0], s[1], s[2], s[3]);
+  }
+  __syncthreads();
+  const float bias = b6[0];
+  float bce_sum = 0.f, dl_sum = 0.f;
+  for (int o = threadIdx.x; o < IMG * IMG; o += D6_THREADS) {
+    const int oy = o / IMG, ox = o - oy * IMG;
+    float a = bias;
+#pragma unroll
+    for (int ky = 0; ky < 2; ++ky) {
+      const int iy = oy - ky;
+      if (iy < 0 || iy >= D5H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 2; ++kx) {
+        const int ix = ox - kx;
+        if (ix < 0 || ix >= D5H) continue;
+        a += d[(iy * D5H + ix) * 4 + ky * 2 + kx];
+      }
+    }
+    const long long oi = (long long)n * (IMG * IMG) + o;
+    const float e = expf(-fabsf(a));
+    const float sg = (a >= 0.f) ? 1.f / (1.f + e) : e / (1.f + e);
+    if (logits != nullptr) logits[oi] = a;
+    if (recon != nullptr) recon[oi] = sg;
+    if (target != nullptr) {
+      const float t = target[oi];
+      bce_sum += fmaxf(a, 0.f) - a * t + log1pf(e);
+      const float dl = (sg - t) * inv_batch;
+      dl_sum += dl;
+      if (dlogit != nullptr) dlogit[oi] = dl;
+    }
+  }
+  bce_sum = wave_sum(bce_sum);
+  dl_sum = wave_sum(dl_sum);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { redbuf[wv] = bce_sum; redbuf[D6_THREADS / 64 + wv] = dl_sum; }
+  __syncthreads();
+  if (threadIdx.x == 0 && rec_b != nullptr) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < D6_THREADS / 64; ++i) { s1 += redbuf[i]; s2 += redbuf[D6_THREADS / 64 + i]; }
+    rec_b[n] = s1;
+    if (dlsum_b != nullptr) dlsum_b[n] = s2;
+  }
+}
+
+// deconv6 backward fused with BN5/ReLU backward, one block per sample.
+//   g[iy][ix][ci]   = sum_{ky,kx} dlogit[iy+ky][ix+kx] * W6[ky][kx][ci]      (= dL/d y5)
+//   dpre5           = (a5 > 0) ? g * scale5 : 0
+//   slab[n][0..3]   = sum_pix y5 * dlogit[tap]   (dW6 partial),  slab[n][4..6] = S1,S2,S3 of BN5 backward
+__global__ __launch_bounds__(D6_THREADS) void deconv6_bwd_kernel(
+    const float* __restrict__ dlogit, const float* __restrict__ a5, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ W6, float* __restrict__ dpre5,
+    float* __restrict__ slab) {
+  __shared__ __attribute__((aligned(16))) float dl[IMG * IMG];
+  __shared__ __attribute__((aligned(16))) float red[(D6_THREADS / 16) * 7 * NCH];
+  const int n = blockIdx.x;
+  const int cq = threadIdx.x & 15, pg = threadIdx.x >> 4;
+  constexpr int NPG = D6_THREADS / 16;
+  for (int i = threadIdx.x; i < IMG * IMG; i += D6_THREADS) dl[i] = dlogit[(long long)n * (IMG * IMG) + i];
+  float4 w[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) w[t] = *reinterpret_cast<const float4*>(W6 + t * NCH + 4 * cq);
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (scale != nullptr) {
+    sc = *reinterpret_cast<const float4*>(scale + 4 * cq);
+    sh = *reinterpret_cast<const float4*>(shift + 4 * cq);
+  }
+  float4 acc[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  const float* src = a5 + (long long)n * (D5H * D5H * NCH);
+  float* dst = dpre5 + (long long)n * (D5H * D5H * NCH);
+  for (int pix = pg; pix < D5H * D5H; pix += NPG) {
+    const int iy = pix / D5H, ix = pix - iy * D5H;
+    const float4 a = *reinterpret_cast<const float4*>(src + pix * NCH + 4 * cq);
+    float4 y;
+    y.x = fmaf(a.x, sc.x, sh.x); y.y = fmaf(a.y, sc.y, sh.y); y.z = fmaf(a.z, sc.z, sh.z); y.w = fmaf(a.w, sc.w, sh.w);
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float dv = dl[(iy + (t >> 1)) * IMG + ix + (t & 1)];
+      g.x = fmaf(dv, w[t].x, g.x); g.y = fmaf(dv, w[t].y, g.y); g.z = fmaf(dv, w[t].z, g.z); g.w = fmaf(dv, w[t].w, g.w);
+      acc[t].x = fmaf(dv, y.x, acc[t].x); acc[t].y = fmaf(dv, y.y, acc[t].y);
+      acc[t].z = fmaf(dv, y.z, acc[t].z); acc[t].w = fmaf(dv, y.w, acc[t].w);
+    }
+    acc[4].x += g.x; acc[4].y += g.y; acc[4].z += g.z; acc[4].w += g.w;
+    acc[5].x = fmaf(g.x, a.x, acc[5].x); acc[5].y = fmaf(g.y, a.y, acc[5].y);
+    acc[5].z = fmaf(g.z, a.z, acc[5].z); acc[5].w = fmaf(g.w, a.w, acc[5].w);
+    float4 o;
+    o.x = (a.x > 0.f) ? g.x : 0.f; o.y = (a.y > 0.f) ? g.y : 0.f;
+    o.z = (a.z > 0.f) ? g.z : 0.f; o.w = (a.w > 0.f) ? g.w : 0.f;
+    acc[6].x += o.x; acc[6].y += o.y; acc[6].z += o.z; acc[6].w += o.w;
+    o.x *= sc.x; o.y *= sc.y; o.z *= sc.z; o.w *= sc.w;
+    *reinterpret_cast<float4*>(dst + pix * NCH + 4 * cq) = o;
+  }
+#pragma unroll
+  for (int t = 0; t < 7; ++t) *reinterpret_cast<float4*>(red + (pg * 7 + t) * NCH + 4 * cq) = acc[t];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 7 * NCH; i += D6_THREADS) {
+    float s = 0.f;
+    for (int g2 = 0; g2 < NPG; ++g2) s += red[g2 * 7 * NCH + i];
+    slab[(long long)n * (7 * NCH) + i] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Philox-4x32-10 (Salmon et al. 2011) + Box-Muller; element e of the (sample, latent) grid
+// uses counter e>>2 and output lane e&3, so epsilon is independent of batch split / world size.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float philox_normal(unsigned long long e, unsigned k0, unsigned k1) {
+  unsigned c0 = (unsigned)((e >> 2) & 0xFFFFFFFFull), c1 = (unsigned)(e >> 34), c2 = 0u, c3 = 0u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const unsigned n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  const int sel = (int)(e & 3ull);
+  const unsigned ua = (sel < 2) ? c0 : c2, ub = (sel < 2) ? c1 : c3;
+  const float u1 = ((float)ua + 0.5f) * (1.0f / 4294967296.0f);
+  const float u2 = ((float)ub + 0.5f) * (1.0f / 4294967296.0f);
+  // (float)ua rounds to 2^32 for the top 128 values -> u1 could be 1.0: log(1)=0, still finite
+  const float rad = sqrtf(-2.0f * logf(fminf(u1, 0.99999994f)));
+  const float th = 6.28318530717958647692f * u2;
+  return (sel & 1) ? rad * sinf(th) : rad * cosf(th);
+}
+
+// z = mu + exp(0.5*lv)*eps ; kl_b = -0.5 * sum_l (1 + lv - mu^2 - exp(lv));  one wave per sample.
+// mulv: [B][2L] (z_mean | z_log_var).  eps: read when use_philox==0, written otherwise.
+__global__ __launch_bounds__(64) void reparam_kl_fwd_kernel(const float* __restrict__ mulv, float* __restrict__ eps,
+                                                            float* __restrict__ z, float* __restrict__ kl_b, int L,
+                                                            int use_philox, unsigned long long seed,
+                                                            unsigned long long first_sample) {
+  const int b = blockIdx.x;
+  float kl = 0.f;
+  for (int l = threadIdx.x; l < L; l += 64) {
+    const float mu = mulv[(long long)b * 2 * L + l];
+    const float lv = mulv[(long long)b * 2 * L + L + l];
+    float e;
+    if (use_philox) {
+      e = philox_normal((first_sample + (unsigned long long)b) * (unsigned long long)L + l,
+                        (unsigned)(seed & 0xFFFFFFFFull), (unsigned)(seed >> 32));
+      eps[(long long)b * L + l] = e;
+    } else {
+      e = eps[(long long)b * L + l];
+    }
+    z[(long long)b * L + l] = fmaf(expf(0.5f * lv), e, mu);
+    kl += -0.5f * (1.f + lv - mu * mu - expf(lv));
+  }
+  kl = wave_sum(kl);
+  if (threadIdx.x == 0 && kl_b != nullptr) kl_b[b] = kl;
+}
+
+// d mu = dz + mu/B ;  d lv = dz*0.5*exp(0.5 lv)*eps + 0.5*(exp(lv)-1)/B     
+__global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ mulv,
+                                                             const float* __restrict__ eps, float* __restrict__ dmulv,
+                                                             int B, int L, float inv_batch) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * L) return;
+  const int b = i / L, l = i - b * L;
+  const float mu = mulv[(long long)b * 2 * L + l];
+  const float lv = mulv[(long long)b * 2 * L + L + l];
+  const float g = dz[i], e = eps[i];
+  dmulv[(long long)b * 2 * L + l] = fmaf(mu, inv_batch, g);
+  dmulv[(long long)b * 2 * L + L + l] = g * 0.5f * expf(0.5f * lv) * e + 0.5f * (expf(lv) - 1.f) * inv_batch;
+}
+
+// ---------------------------------------------------------------------------------------
+// BatchNorm (inference mode) helpers
+// ---------------------------------------------------------------------------------------
+__global__ void bn_prepare_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                  const float* __restrict__ mean, const float* __restrict__ var,
+                                  float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ rstd,
+                                  int n, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float r = 1.0f / sqrtf(var[i] + eps);
+  const float s = gamma[i] * r;
+  scale[i] = s;
+  shift[i] = fmaf(-mean[i], s, beta[i]);
+  rstd[i] = r;
+}
+
+// Elementwise BN/ReLU backward over g[R][C]: out = (aux>0) ? g*scale[c] : 0, with per-row-chunk
+// column sums S1 = sum g, S2 = sum g*aux, S3 = sum masked g  -> partials[chunk][3][C].
+// aux == nullptr: no mask, S2 = 0 (plain column sum, e.g. bias gradient of a linear layer).
+#define BRB_ROWS 32
+__global__ __launch_bounds__(256) void bnrelu_bwd_rows_kernel(const float* __restrict__ g, const float* __restrict__ aux,
+                                                              const float* __restrict__ e_scale, float* __restrict__ out,
+                                                              float* __restrict__ partials, int R, int C, int cmask) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int r0 = blockIdx.y * BRB_ROWS, r1 = min(R, r0 + BRB_ROWS);
+  const float sc = (e_scale != nullptr) ? e_scale[c & cmask] : 1.f;
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const long long i = (long long)r * C + c;
+    const float v = g[i];
+    float a = 1.f;
+    if (aux != nullptr) { a = aux[i]; s2 = fmaf(v, a, s2); }
+    const bool on = a > 0.f;
+    s1 += v;
+    s3 += on ? v : 0.f;
+    if (out != nullptr) out[i] = on ? v * sc : 0.f;
+  }
+  if (partials != nullptr) {
+    float* pp = partials + (long long)blockIdx.y * 3 * C + c;
+    pp[0] = s1; pp[C] = s2; pp[2 * C] = s3;
+  }
+}
+
+// Column-sum finalisation: channel ch collects every column j with (j % nch) == ch over all
+// T partial rows.  dbeta = S1, dgamma = rstd*(S2 - mean*S1), dbias = escale*S3.
+// partial element (t,k,j) lives at partials[t*row_stride + k*ncols + j].  One block per channel.
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partials, int T,
+                                                              long long row_stride, int ncols, int nch,
+                                                              const float* __restrict__ e_scale,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              float* __restrict__ dbias, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta) {
+  __shared__ float red[3 * 4];
+  const int ch = blockIdx.x;
+  const int nrep = ncols / nch;
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const int total = T * nrep;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int t = i / nrep, rep = i - t * nrep;
+    const float* pp = partials + (long long)t * row_stride + rep * nch + ch;
+    s1 += pp[0]; s2 += pp[ncols]; s3 += pp[2 * ncols];
+  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[wv] = s1; red[4 + wv] = s2; red[8 + wv] = s3; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s1 = red[0] + red[1] + red[2] + red[3];
+    s2 = red[4] + red[5] + red[6] + red[7];
+    s3 = red[8] + red[9] + red[10] + red[11];
+    if (dbias != nullptr) dbias[ch] = (e_scale != nullptr) ? e_scale[ch] * s3 : s3;
+    if (dbeta != nullptr) dbeta[ch] = s1;
+    if (dgamma != nullptr) dgamma[ch] = rstd[ch] * (s2 - mean[ch] * s1);
+  }
+}
+
+// out[i] = epi( sum_s slab[s*stride + i] ),  epi = (+bias[i % ncols]) (relu)
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slab, int nsplit, long long stride,
+                                                       long long n, float* __restrict__ out,
+                                                       const float* __restrict__ bias, int ncols, int relu) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slab[(long long)k * stride + i];
+    if (bias != nullptr) s += bias[(int)(i % ncols)];
+    if (relu) s = fmaxf(s, 0.f);
+    out[i] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// keras.optimizers.legacy.Adam: epsilon outside the bias correction.
+// state[0] = step count t (as float bits of an int), alpha written to state_alpha.
+// ---------------------------------------------------------------------------------------
+__global__ void adam_prepare_kernel(int* __restrict__ step, float* __restrict__ alpha, float lr, float b1, float b2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int t = step[0] + 1;
+    step[0] = t;
+    const double a = (double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t));
+    alpha[0] = (float)a;
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_apply_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v, long long n4,
+                                                         const float* __restrict__ alpha_p, float gscale, float b1,
+                                                         float b2, float eps) {
+  const float alpha = alpha_p[0];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    gg.x *= gscale; gg.y *= gscale; gg.z *= gscale; gg.w *= gscale;
+    mm.x = b1 * mm.x + (1.f - b1) * gg.x; mm.y = b1 * mm.y + (1.f - b1) * gg.y;
+    mm.z = b1 * mm.z + (1.f - b1) * gg.z; mm.w = b1 * mm.w + (1.f - b1) * gg.w;
+    vv.x = b2 * vv.x + (1.f - b2) * gg.x * gg.x; vv.y = b2 * vv.y + (1.f - b2) * gg.y * gg.y;
+    vv.z = b2 * vv.z + (1.f - b2) * gg.z * gg.z; vv.w = b2 * vv.w + (1.f - b2) * gg.w * gg.w;
+    pp.x -= alpha * mm.x / (sqrtf(vv.x) + eps); pp.y -= alpha * mm.y / (sqrtf(vv.y) + eps);
+    pp.z -= alpha * mm.z / (sqrtf(vv.z) + eps); pp.w -= alpha * mm.w / (sqrtf(vv.w) + eps);
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+}
+
+// losses[0..2] = total, rec, kl (means over the local batch); metrics[0..2] += those, metrics[3] += 1;
+// db6 = sum_b dlsum_b (bias gradient of deconv6).  Single block.
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ rec_b, const float* __restrict__ kl_b,
+                                                            const float* __restrict__ dlsum_b, int B,
+                                                            float* __restrict__ losses, float* __restrict__ metrics,
+                                                            float* __restrict__ db6) {
+  __shared__ double red[3 * 4];
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  for (int i = threadIdx.x; i < B; i += 256) {
+    s1 += (double)rec_b[i];
+    if (kl_b != nullptr) s2 += (double)kl_b[i];
+    if (dlsum_b != nullptr) s3 += (double)dlsum_b[i];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); s3 += __shfl_xor(s3, o); }
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[wv] = s1; red[4 + wv] = s2; red[8 + wv] = s3; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s1 = red[0] + red[1] + red[2] + red[3];
+    s2 = red[4] + red[5] + red[6] + red[7];
+    s3 = red[8] + red[9] + red[10] + red[11];
+    const float rec = (float)(s1 / B), kl = (float)(s2 / B);
+    if (losses != nullptr) { losses[0] = rec + kl; losses[1] = rec; losses[2] = kl; }
+    if (metrics != nullptr) { metrics[0] += rec + kl; metrics[1] += rec; metrics[2] += kl; metrics[3] += 1.f; }
+    if (db6 != nullptr) db6[0] = (float)s3;
+  }
+}
+
+// Attribution seed: d(pre-activation of the encoder dense) for target latent unit j.
+//  VAE: dpre[b][i] = (h[b][i] > 0) ? Whead[i][j] : 0      (z_mean column j of the [100][2L] head matrix)
+//  AE : dpre[b][i] = (i == j && h[b][i] > 0) ? 1 : 0
+__global__ __launch_bounds__(256) void attr_seed_kernel(const float* __restrict__ h, const float* __restrict__ whead,
+                                                        float* __restrict__ dpre, int B, int H, int ldw, int unit,
+                                                        int is_ae) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * H) return;
+  const int col = i % H;
+  const bool on = h[i] > 0.f;
+  float v;
+  if (is_ae) v = (col == unit && on) ? 1.f : 0.f;
+  else v = on ? whead[col * ldw + unit] : 0.f;
+  dpre[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------
+static inline int grid_for(long long work, int per_block, int cap) {
+  long long g = (work + per_block - 1) / per_block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" {
+
+int veex_conv1_fwd(const float* x, const float* W, const float* bias, float* out, int B, hipStream_t st) {
+  const int npix = B * C1H * C1H;
+  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(grid_for(npix, 16, 4096)), dim3(256), 0, st, x, W, bias, out, npix);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+int veex_conv1_wgrad_blocks(int B) { return grid_for((long long)B * C1H * C1H, 16 * 8, 1024); }
+
+int veex_conv1_wgrad(const float* x, const float* dpre, float* slab, int B, hipStream_t st) {
+  const int npix = B * C1H * C1H;
+  hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(veex_conv1_wgrad_blocks(B)), dim3(256), 0, st, x, dpre, slab, npix);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+int veex_conv1_dgrad(const float* dpre, const float* W, const float* mul, float* dx, int B, hipStream_t st) {
+  const int npix = B * IMG * IMG;
+  hipLaunchKernelGGL(conv1_dgrad_kernel, dim3(grid_for(npix, 16, 8192)), dim3(256), 0, st, dpre, W, mul, dx, npix);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+int veex_deconv6_bce_fwd(const float* a5, const float* scale, const float* shift, const float* W6, const float* b6,
+                          const float* target, float* logits, float* recon, float* dlogit, float* rec_b,
+                          float* dlsum_b, int B, float inv_batch, hipStream_t st) {
+  hipLaunchKernelGGL(deconv6_bce_fwd_kernel, dim3(B), dim3(D6_THREADS), 0, st, a5, scale, shift, W6, b6, target, logits,
+                     recon, dlogit, rec_b, dlsum_b, inv_batch);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+int veex_deconv6_bwd(const float* dlogit, const float* a5, const float* scale, const float* shift, const float* W6,
+                      float* dpre5, float* slab, int B, hipStream_t st) {
+  hipLaunchKernelGGL(deconv6_bwd_kernel, dim3(B), dim3(D6_THREADS), 0, st, dlogit, a5, scale, shift, W6, dpre5, slab);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+int veex_reparam_kl_fwd(const float* mulv, float* eps, float* z, float* kl_b, int B, int L, int use_philox,
+                         unsigned long long seed, unsigned long long first_sample, hipStream_t st) {
+  hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3(B), dim3(64), 0, st, mulv, eps, z, kl_b, L, use_philox, seed,
+                     first_sample);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+int veex_reparam_kl_bwd(const float* dz, const float* mulv, const float* eps, float* dmulv, int B, int L,
+                         float inv_batch, hipStream_t st) {
+  hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3((B * L + 255) / 256), dim3(256), 0, st, dz, mulv, eps, dmulv, B, L,
+                     inv_batch);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+int veex_bn_prepare(const float* gamma, const float* beta, const float* mean, const float* var, float* scale,
+                     float* shift, float* rstd, int n, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(bn_prepare_kernel, dim3((n + 255) / 256), dim3(256), 0, st, gamma, beta, mean, var, scale, shift,
+                     rstd, n, eps);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+int veex_bnrelu_bwd_rows_chunks(int R) { return (R + BRB_ROWS - 1) / BRB_ROWS; }
+
+int veex_bnrelu_bwd_rows(const float* g, const float* aux, const float* e_scale, float* out, float* partials, int R,
+                          int C, int e_channels, hipStream_t st) {
+  if (e_scale != nullptr && (e_channels <= 0 || (e_channels & (e_channels - 1)) != 0)) {
+    veex_set_error("bnrelu_bwd_rows: e_channels must be a power of two");
+    return -1;
+  }
+  const int cmask = (e_scale != nullptr) ? e_channels - 1 : 0;
+  hipLaunchKernelGGL(bnrelu_bwd_rows_kernel, dim3((C + 255) / 256, veex_bnrelu_bwd_rows_chunks(R)), dim3(256), 0, st, g, aux,
+                     e_scale, out, partials, R, C, cmask);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+int veex_colsum_finalize(const float* partials, int T, long long row_stride, int ncols, int nch, const float* e_scale,
+                          const float* mean, const float* rstd, float* dbias, float* dgamma, float* dbeta,
+                          hipStream_t st) {
+  if (nch <= 0 || ncols % nch != 0) {
+    veex_set_error("colsum_finalize: channel count %d must divide ncols %d", nch, ncols);
+    return -1;
+  }
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(nch), dim3(256), 0, st, partials, T, row_stride, ncols, nch, e_scale,
+                     mean, rstd, dbias, dgamma, dbeta);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+int veex_slab_sum(const float* slab, int nsplit, long long stride, long long n, float* out, const float* bias,
+                   int ncols, int relu, hipStream_t st) {
+  hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, slab, nsplit, stride, n, out, bias,
+                     ncols, relu);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+int veex_adam(float* p, const float* g, float* m, float* v, long long n, int* step, float* alpha, float lr,
+               float gscale, float b1, float b2, float eps, hipStream_t st) {
+  if (n % 4 != 0) { veex_set_error("adam: element count must be a multiple of 4"); return -1; }
+  hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, st, step, alpha, lr, b1, b2);
+  hipLaunchKernelGGL(adam_apply_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, st, p, g, m, v, n / 4, alpha,
+                     gscale, b1, b2, eps);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+int veexi_loss_finalize(const float* rec_b, const float* kl_b, const float* dlsum_b, int B, float* losses,
+                        float* metrics, float* db6, hipStream_t st) {
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, rec_b, kl_b, dlsum_b, B, losses, metrics, db6);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+int veexi_attr_seed(const float* h, const float* whead, float* dpre, int B, int H, int ldw, int unit, int is_ae,
+                    hipStream_t st) {
+  hipLaunchKernelGGL(attr_seed_kernel, dim3((B * H + 255) / 256), dim3(256), 0, st, h, whead, dpre, B, H, ldw, unit,
+                     is_ae);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

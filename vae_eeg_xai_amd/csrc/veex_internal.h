@@ -1,0 +1,78 @@
+// Internal (non-ABI) declarations shared by the veex HIP translation units.
+// gfx950 / CDNA4 only.  The public C-ABI is include/veex.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define VEEX_BK 16          // K-chunk of every MFMA GEMM tile (floats)
+#define VEEX_LDK 20         // padded k-stride of [row][k] LDS tiles (16 + one b128)
+
+enum { VEEX_EPI_FWD = 0, VEEX_EPI_BWD = 1, VEEX_EPI_RAW = 2 };
+
+// ---------------------------------------------------------------------------
+// Gather-GEMM (implicit GEMM for Conv2D / Conv2DTranspose / Dense, forward and dgrad)
+//   Out[m][n] = sum_{tap, ci} Aval(m, tap, ci) * Wval(tap, ci, n)
+// mode 0 (conv-gather):   in = stride*out + k - pb     (Conv2D fwd, Conv2DTranspose dgrad, Dense)
+// mode 1 (deconv-gather): in = (out + pb - k)/stride   (Conv2DTranspose fwd, Conv2D dgrad, Dense dgrad)
+// Weight memory: mode 0 -> [tap][Cin][Cout]  (n contiguous);  mode 1 -> [tap][Cout][Cin] (k contiguous)
+// ---------------------------------------------------------------------------
+struct GGParams {
+  const float* A;        // gathered operand, NHWC [Nb][Hin][Win][Cin]
+  const float* W;
+  float* Out;            // NHWC [Nb][Hout][Wout][Cout]; RAW: slab base [nsplit][same]
+  const float* a_scale;  // optional per-channel affine applied to in-bounds A loads (producer's BN)
+  const float* a_shift;
+  const float* bias;     // EPI_FWD (nullable)
+  const float* aux;      // EPI_BWD: post-ReLU activation of the layer being differentiated
+  const float* e_scale;  // EPI_BWD: BN scale of that layer (nullable -> 1)
+  float* partials;       // EPI_BWD: [m_tiles][3][Cout] column partial sums (nullable)
+  int Nb, Hin, Win, Cin, Hout, Wout, Cout;
+  int kh, kw, stride, pb;
+  int mode;
+  int aff_mask, aff_spatial;
+  int epi, relu, epi_cmask;
+  int nsplit, chunks_per_split;
+  int nphase;            // 1, or 4 for stride-2 deconv-gather (sub-pixel phases)
+  int tile_prefix[5];    // cumulative m-tiles per phase
+  int Hp[2], Wp[2];      // rows / cols of each parity class (nphase==1: Hp[0]=Hout, Wp[0]=Wout)
+  int o0[2];             // first output coordinate of parity class p
+  long long slab_stride; // elements per split slab (RAW)
+};
+
+// ---------------------------------------------------------------------------
+// Weight-gradient GEMM:  dW[tap][cb][cs] = sum_{n,py,px} Big(n, s*py+ky-pb, s*px+kx-pb, cb) * Small(n,py,px,cs)
+// Conv2D: Big = layer input, Small = d(pre-activation);  Conv2DTranspose: Big = d(pre-act), Small = layer input.
+// ---------------------------------------------------------------------------
+struct WGParams {
+  const float* Big;
+  const float* Small;
+  float* Out;            // [nsplit][M][Cs] partial slabs (nsplit==1: the gradient itself)
+  const float* b_scale; const float* b_shift;
+  const float* s_scale; const float* s_shift;
+  int b_aff_mask, b_aff_spatial, s_aff_mask, s_aff_spatial;
+  int Nb, Hb, Wb, Cb, Hs, Ws, Cs;
+  int kh, kw, stride, pb;
+  int R;                 // Nb*Hs*Ws reduction rows
+  int rows_per_split;    // multiple of VEEX_BK
+  int M;                 // kh*kw*Cb
+  int nsplit;
+};
+
+// launchers (host side; enqueue only, no sync, no allocation)
+int veex_launch_gather_gemm(const GGParams& p, hipStream_t st);
+int veex_launch_wgrad(const WGParams& p, hipStream_t st);
+int veex_gg_m_tiles(GGParams& p);   // fills phase tables; returns total m tiles for the chosen config
+int veex_gg_bm(int Cout, long long M);
+int veex_wg_tiles(const WGParams& p, int* bm, int* bn);
+
+void veex_set_error(const char* fmt, ...);
+
+#define VEEX_CHECK_LAUNCH()                                        \
+  do {                                                             \
+    hipError_t e__ = hipGetLastError();                            \
+    if (e__ != hipSuccess) {                                       \
+      veex_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+      return -3;                                                   \
+    }                                                              \
+  } while (0)

@@ -1,0 +1,233 @@
+// Weight-gradient GEMM on the exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+//   dW[tap][cb][cs] = sum_{n,py,px} Big(n, s*py+ky-pb, s*px+kx-pb, cb) * Small(n,py,px,cs)
+//
+// Conv2D (kernel (kh,kw,Cin,Cout)):            Big = layer input,  Small = d(pre-activation)
+// Conv2DTranspose (kernel (kh,kw,Cout,Cin)):   Big = d(pre-act),   Small = layer input
+// Dense (kernel (in,out)):                     1 tap, Big = input, Small = d(pre-act)
+// (the reference obtains these from tape.gradient, models.py:166).
+//
+// The reduction runs over pixels (B*Hs*Ws, up to ~10^6), the output is small, so the grid is
+// split along the reduction; every split writes its own [M][Cs] slab with plain stores and a
+// second kernel sums the slabs in a fixed order (bitwise reproducible, no float atomics).
+// Either operand may carry the producer's BatchNorm affine (applied while staging, in-bounds
+// pixels only).
+#include "veex_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float4 wld4(const float* ptr, bool ok, int nvalid, bool vec) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) {
+    if (vec && nvalid >= 4) {
+      v = *reinterpret_cast<const float4*>(ptr);
+    } else {
+      if (nvalid > 0) v.x = ptr[0];
+      if (nvalid > 1) v.y = ptr[1];
+      if (nvalid > 2) v.z = ptr[2];
+      if (nvalid > 3) v.w = ptr[3];
+    }
+  }
+  return v;
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WGParams p) {
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MT = WTM / 32, NT = WTN / 32;
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int A_ELEMS = VEEX_BK * LDA, B_ELEMS = VEEX_BK * LDB;
+  constexpr int QM = BM / 4, QN = BN / 4;
+  constexpr int RPA = 256 / QM, RPB = 256 / QN;       // reduction rows staged per pass
+  constexpr int APASS = VEEX_BK / RPA, BPASS = VEEX_BK / RPB;
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(APASS >= 1 && BPASS >= 1, "tile too small");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                  // [2][16][BM+4]  (reduction row major, m contiguous)
+  float* Bs = smem + 2 * A_ELEMS;    // [2][16][BN+4]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lh = lane >> 5, l31 = lane & 31;
+
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int r_begin = blockIdx.z * p.rows_per_split;
+  const int r_end = min(p.R, r_begin + p.rows_per_split);
+  const int nchunks = (r_end > r_begin) ? (r_end - r_begin + VEEX_BK - 1) / VEEX_BK : 0;
+
+  // A loader: m-quad fixed per thread
+  const int amq = tid % QM, arow = tid / QM;
+  const int am = m0 + 4 * amq;
+  const bool vecA = ((p.Cb & 3) == 0);
+  const bool vecB = ((p.Cs & 3) == 0);
+  int a_ky[4], a_kx[4], a_cb[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int m = am + e;
+    const int tap = m / p.Cb;
+    a_cb[e] = m - tap * p.Cb;
+    a_ky[e] = tap / p.kw;
+    a_kx[e] = tap - a_ky[e] * p.kw;
+  }
+  const int bnq = tid % QN, brow = tid / QN;
+  const int bn = n0 + 4 * bnq;
+  const int HWs = p.Hs * p.Ws;
+
+  float4 ra[APASS], rb[BPASS];
+
+  auto load_chunk = [&](int c) {
+    const int rbase = r_begin + c * VEEX_BK;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      const int r = rbase + arow + RPA * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < r_end && am < p.M) {
+        const int n = r / HWs, rem = r - n * HWs;
+        const int py = rem / p.Ws, px = rem - py * p.Ws;
+        if (vecA) {
+          const int by = p.stride * py + a_ky[0] - p.pb, bx = p.stride * px + a_kx[0] - p.pb;
+          if (by >= 0 && by < p.Hb && bx >= 0 && bx < p.Wb) {
+            const int pix = by * p.Wb + bx;
+            v = *reinterpret_cast<const float4*>(p.Big + ((long long)(n * p.Hb * p.Wb + pix)) * p.Cb + a_cb[0]);
+            if (p.b_scale != nullptr) {
+              const int aidx = (a_cb[0] + (p.b_aff_spatial ? pix * p.Cb : 0)) & p.b_aff_mask;
+              const float4 sc = *reinterpret_cast<const float4*>(p.b_scale + aidx);
+              const float4 sh = *reinterpret_cast<const float4*>(p.b_shift + aidx);
+              v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+              v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+            }
+          }
+        } else {
+          float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (am + e >= p.M) continue;
+            const int by = p.stride * py + a_ky[e] - p.pb, bx = p.stride * px + a_kx[e] - p.pb;
+            if (by < 0 || by >= p.Hb || bx < 0 || bx >= p.Wb) continue;
+            const int pix = by * p.Wb + bx;
+            float x = p.Big[((long long)(n * p.Hb * p.Wb + pix)) * p.Cb + a_cb[e]];
+            if (p.b_scale != nullptr) {
+              const int aidx = (a_cb[e] + (p.b_aff_spatial ? pix * p.Cb : 0)) & p.b_aff_mask;
+              x = fmaf(x, p.b_scale[aidx], p.b_shift[aidx]);
+            }
+            t[e] = x;
+          }
+          v = make_float4(t[0], t[1], t[2], t[3]);
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+      const int r = rbase + brow + RPB * i;
+      const bool ok = r < r_end && bn < p.Cs;
+      float4 v = wld4(p.Small + (long long)r * p.Cs + bn, ok, p.Cs - bn, vecB);
+      if (p.s_scale != nullptr && ok) {
+        const int pix = p.s_aff_spatial ? (r % HWs) : 0;
+        const int aidx = (bn + pix * p.Cs) & p.s_aff_mask;
+        const float4 sc = wld4(p.s_scale + aidx, true, p.Cs - bn, vecB);
+        const float4 sh = wld4(p.s_shift + aidx, true, p.Cs - bn, vecB);
+        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+        v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+      }
+      rb[i] = v;
+    }
+  };
+
+  auto store_chunk = [&](int buf) {
+    float* as = As + buf * A_ELEMS;
+    float* bs = Bs + buf * B_ELEMS;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i)
+      *reinterpret_cast<float4*>(as + (arow + RPA * i) * LDA + 4 * amq) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i)
+      *reinterpret_cast<float4*>(bs + (brow + RPB * i) * LDB + 4 * bnq) = rb[i];
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nchunks > 0) {
+    load_chunk(0);
+    store_chunk(0);
+  }
+  __syncthreads();
+
+  for (int c = 0; c < nchunks; ++c) {
+    const int cur = c & 1;
+    const bool more = (c + 1 < nchunks);
+    if (more) load_chunk(c + 1);
+    const float* as = As + cur * A_ELEMS + (8 * lh) * LDA + wm * WTM + l31;
+    const float* bs = Bs + cur * B_ELEMS + (8 * lh) * LDB + wn * WTN + l31;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      float av[MT], bv[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) av[i] = as[kk * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bv[j] = bs[kk * LDB + j * 32];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_chunk(cur ^ 1);
+    __syncthreads();
+  }
+
+  float* outp = p.Out + (long long)blockIdx.z * p.M * p.Cs;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + wn * WTN + j * 32 + l31;
+    if (col >= p.Cs) continue;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < p.M) outp[(long long)m * p.Cs + col] = acc[i][j][r];
+      }
+    }
+  }
+}
+
+int veex_wg_tiles(const WGParams& p, int* bm, int* bn) {
+  *bn = (p.Cs > 64) ? 128 : 64;
+  *bm = (p.M > 64) ? 128 : 64;
+  const int mt = (p.M + *bm - 1) / *bm, nt = (p.Cs + *bn - 1) / *bn;
+  return mt * nt;
+}
+
+template <int BM, int BN>
+static int wg_launch_cfg(const WGParams& p, hipStream_t st) {
+  dim3 grid((p.M + BM - 1) / BM, (p.Cs + BN - 1) / BN, p.nsplit);
+  constexpr size_t lds = 2 * VEEX_BK * ((BM + 4) + (BN + 4)) * sizeof(float);
+  hipLaunchKernelGGL((wgrad_kernel<BM, BN, 2, 2>), grid, dim3(256), lds, st, p);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+int veex_launch_wgrad(const WGParams& p, hipStream_t st) {
+  if (p.stride != 1 && p.stride != 2) { veex_set_error("wgrad: stride %d unsupported", p.stride); return -1; }
+  if (p.M != p.kh * p.kw * p.Cb || p.R != p.Nb * p.Hs * p.Ws || p.nsplit < 1 ||
+      (p.rows_per_split % VEEX_BK) != 0 || (long long)p.rows_per_split * p.nsplit < p.R) {
+    veex_set_error("wgrad: inconsistent descriptor (M=%d R=%d nsplit=%d rows_per_split=%d)", p.M, p.R, p.nsplit, p.rows_per_split);
+    return -1;
+  }
+  if (p.kh * p.kw > 1 && (p.Cb & 3) != 0) { veex_set_error("wgrad: multi-tap layers need Cb %% 4 == 0"); return -1; }
+  int bm, bn;
+  veex_wg_tiles(p, &bm, &bn);
+  if (bm == 128 && bn == 128) return wg_launch_cfg<128, 128>(p, st);
+  if (bm == 128 && bn == 64) return wg_launch_cfg<128, 64>(p, st);
+  if (bm == 64 && bn == 128) return wg_launch_cfg<64, 128>(p, st);
+  return wg_launch_cfg<64, 64>(p, st);
+}

@@ -1,0 +1,274 @@
+"""Device-resident state of one reference network and the whole-step calls into libveex.so.
+
+``Net`` owns the flat fp32 buffers in HBM (trainable parameters, gradients, Adam moments,
+BatchNorm moving statistics, workspace) as torch tensors and hands raw pointers + the current
+HIP stream to the C-ABI (include/veex.h).  torch is plumbing only (memory, streams,
+torch.distributed); every arithmetic op of the hot path runs in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr
+
+ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-7   # keras legacy Adam defaults (train.py:9,137)
+
+
+class TensorSpec:
+    __slots__ = ("name", "offset", "shape", "trainable", "part")
+
+    def __init__(self, name, offset, shape, trainable, part):
+        self.name, self.offset, self.shape, self.trainable, self.part = name, offset, shape, trainable, part
+
+
+def _as_device_f32(a, device) -> torch.Tensor:
+    if isinstance(a, torch.Tensor):
+        t = a.detach()
+    elif hasattr(a, "_t") and isinstance(getattr(a, "_t"), torch.Tensor):   # DeviceArray
+        t = a._t
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32)))
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class Net:
+    """One VAE (variant 'vae', models.py) or plain autoencoder ('ae', models_standard.py)."""
+
+    def __init__(self, latent_dim: int, variant: str = "vae", device: Optional[str] = None):
+        if not torch.cuda.is_available():
+            raise _lib.VeexError("no GPU visible: vae_eeg_xai_amd has no CPU path")
+        self.device = torch.device(device or f"cuda:{torch.cuda.current_device()}")
+        self.latent_dim = int(latent_dim)
+        self.variant = variant
+        self._h = lib.veex_net_create(self.latent_dim, _lib.VARIANT_VAE if variant == "vae" else _lib.VARIANT_AE)
+        if not self._h:
+            raise _lib.VeexError(lib.veex_last_error().decode())
+        self.n_params = lib.veex_net_param_floats(self._h)
+        self.n_state = lib.veex_net_state_floats(self._h)
+        self.specs: List[TensorSpec] = []
+        name = C.create_string_buffer(128)
+        off, nd, tr, part = C.c_longlong(), C.c_int(), C.c_int(), C.c_int()
+        shp = (C.c_longlong * 4)()
+        for i in range(lib.veex_net_num_tensors(self._h)):
+            check(lib.veex_net_tensor_info(self._h, i, name, 128, C.byref(off), C.byref(nd), shp, C.byref(tr),
+                                           C.byref(part)), "tensor_info")
+            self.specs.append(TensorSpec(name.value.decode(), off.value, tuple(shp[k] for k in range(nd.value)),
+                                         bool(tr.value), part.value))
+        with torch.cuda.device(self.device):
+            # 4 extra floats at the tail of the gradient buffer carry (total, rec, kl, pad) so that
+            # data-parallel training needs exactly one all-reduce per step
+            self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+            self.grads = torch.zeros(self.n_params + 4, dtype=torch.float32, device=self.device)
+            self.adam_m = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+            self.adam_v = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+            self.state = torch.zeros(self.n_state, dtype=torch.float32, device=self.device)
+            self.adam_step_count = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self.adam_alpha = torch.zeros(1, dtype=torch.float32, device=self.device)
+            self.metrics = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self._ws: Dict[int, torch.Tensor] = {}
+        self.philox_seed = 42
+        self.samples_seen = 0
+        self.reset_bn_state()
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.veex_net_destroy(h)
+            self._h = None
+
+    # ---------------- parameters ----------------
+    def view(self, spec: TensorSpec, buf: Optional[torch.Tensor] = None) -> torch.Tensor:
+        base = buf if buf is not None else (self.params if spec.trainable else self.state)
+        L = self.latent_dim
+        if spec.part == 0:
+            n = int(np.prod(spec.shape))
+            return base[spec.offset:spec.offset + n].view(*spec.shape)
+        lo = 0 if spec.part == 1 else L
+        if len(spec.shape) == 2:      # head kernel: columns [lo, lo+L) of the [100][2L] matrix
+            return base[spec.offset:spec.offset + 100 * 2 * L].view(100, 2 * L)[:, lo:lo + L]
+        return base[spec.offset + lo:spec.offset + lo + L]
+
+    def named_views(self, buf: Optional[torch.Tensor] = None, trainable_only=False):
+        for s in self.specs:
+            if trainable_only and not s.trainable:
+                continue
+            if buf is not None and not s.trainable:
+                continue
+            yield s.name, self.view(s, buf)
+
+    def reset_bn_state(self):
+        for s in self.specs:
+            if not s.trainable:
+                self.view(s).fill_(1.0 if s.name.endswith(".var") else 0.0)
+
+    def init_weights(self, seed: Optional[int] = None):
+        """Keras initialisers of the reference: he_uniform on conv kernels (models.py:217-301),
+        glorot_uniform on Dense kernels, zero biases, BN gamma=1 beta=0 mean=0 var=1."""
+        rng = np.random.default_rng(seed)
+        for s in self.specs:
+            leaf = s.name.rsplit(".", 1)[1]
+            if leaf == "kernel":
+                if len(s.shape) == 4:
+                    lim = np.sqrt(6.0 / (s.shape[0] * s.shape[1] * s.shape[2]))
+                else:
+                    lim = np.sqrt(6.0 / (s.shape[0] + s.shape[1]))
+                v = rng.uniform(-lim, lim, size=s.shape)
+            elif leaf in ("gamma", "var"):
+                v = np.ones(s.shape)
+            else:
+                v = np.zeros(s.shape)
+            self.view(s).copy_(torch.from_numpy(v.astype(np.float32)))
+        self.adam_m.zero_(); self.adam_v.zero_(); self.adam_step_count.zero_()
+
+    def set_weights_dict(self, d: Dict[str, np.ndarray]):
+        for s in self.specs:
+            if s.name in d:
+                self.view(s).copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(d[s.name], dtype=np.float32))))
+
+    def get_weights_dict(self, buf: Optional[torch.Tensor] = None) -> Dict[str, np.ndarray]:
+        return {n: v.detach().cpu().numpy().copy() for n, v in self.named_views(buf)}
+
+    def get_weights(self) -> List[np.ndarray]:
+        """keras Model.get_weights() order: trainable (layer creation order) then non-trainable."""
+        return [self.view(s).detach().cpu().numpy().copy() for s in self.specs]
+
+    def set_weights(self, ws: Sequence[np.ndarray]):
+        if len(ws) != len(self.specs):
+            raise ValueError(f"expected {len(self.specs)} arrays, got {len(ws)}")
+        for s, w in zip(self.specs, ws):
+            w = np.asarray(w, dtype=np.float32)
+            if tuple(w.shape) != tuple(s.shape):
+                raise ValueError(f"{s.name}: shape {w.shape} != {s.shape}")
+            self.view(s).copy_(torch.from_numpy(np.ascontiguousarray(w)))
+
+    # ---------------- workspace ----------------
+    def workspace(self, batch: int) -> torch.Tensor:
+        ws = self._ws.get(batch)
+        if ws is None:
+            n = lib.veex_net_workspace_floats(self._h, batch)
+            if n < 0:
+                raise _lib.VeexError(lib.veex_last_error().decode())
+            ws = torch.zeros(n, dtype=torch.float32, device=self.device)
+            if len(self._ws) > 4:
+                self._ws.clear()
+            self._ws[batch] = ws
+        return ws
+
+    def ws_region(self, batch: int, name: str) -> torch.Tensor:
+        n = C.c_longlong()
+        off = lib.veex_net_ws_offset(self._h, batch, name.encode(), C.byref(n))
+        if off < 0:
+            raise KeyError(name)
+        return self.workspace(batch)[off:off + n.value]
+
+    # ---------------- calls ----------------
+    def _eps_args(self, eps, batch):
+        if self.variant != "vae":
+            return None, 0
+        if eps is None:
+            return None, _lib.F_PHILOX
+        e = _as_device_f32(eps, self.device)
+        if tuple(e.shape) != (batch, self.latent_dim):
+            raise ValueError(f"epsilon shape {tuple(e.shape)} != {(batch, self.latent_dim)}")
+        return e, 0
+
+    def _x(self, x) -> torch.Tensor:
+        t = _as_device_f32(x, self.device)
+        if t.dim() == 4 and t.shape[1:] == (40, 40, 1):
+            pass
+        elif t.dim() == 3 and t.shape[1:] == (40, 40):
+            pass
+        else:
+            raise ValueError(f"expected (B,40,40,1) input, got {tuple(t.shape)}")
+        return t
+
+    def encode(self, x, eps=None):
+        """Encoder.call: returns (z_mean, z_log_var, z) device tensors; AE: (z, None, z)."""
+        x = self._x(x)
+        B, L = x.shape[0], self.latent_dim
+        ws = self.workspace(B)
+        e, flags = self._eps_args(eps, B)
+        z = torch.empty(B, L, dtype=torch.float32, device=self.device)
+        zm = zlv = None
+        if self.variant == "vae":
+            zm, zlv = torch.empty_like(z), torch.empty_like(z)
+        first = self.samples_seen
+        if flags & _lib.F_PHILOX:
+            self.samples_seen += B
+        check(lib.veex_net_encode(self._h, ptr(self.params), ptr(self.state), ptr(x), ptr(e), B, flags,
+                                  self.philox_seed, first, ptr(ws), ws.numel(), ptr(zm), ptr(zlv), ptr(z),
+                                  _lib.current_stream()), "net_encode")
+        return (zm, zlv, z) if self.variant == "vae" else (z, None, z)
+
+    def decode(self, z, want_logits=False):
+        z = _as_device_f32(z, self.device)
+        if z.dim() != 2 or z.shape[1] != self.latent_dim:
+            raise ValueError(f"expected (B,{self.latent_dim}) latent, got {tuple(z.shape)}")
+        B = z.shape[0]
+        ws = self.workspace(B)
+        recon = torch.empty(B, 40, 40, 1, dtype=torch.float32, device=self.device)
+        logits = torch.empty_like(recon) if want_logits else None
+        check(lib.veex_net_decode(self._h, ptr(self.params), ptr(self.state), ptr(z), B, ptr(ws), ws.numel(),
+                                  ptr(recon), ptr(logits), _lib.current_stream()), "net_decode")
+        return (recon, logits) if want_logits else recon
+
+    def forward(self, x, eps=None, want_recon=True, accumulate_metrics=False, zmean_decode=False):
+        """VAE.call + losses (test_step): returns (recon or None, losses[3] device tensor)."""
+        x = self._x(x)
+        B = x.shape[0]
+        ws = self.workspace(B)
+        e, flags = self._eps_args(eps, B)
+        if zmean_decode:
+            flags |= _lib.F_ZMEAN_DECODE
+        recon = torch.empty(B, 40, 40, 1, dtype=torch.float32, device=self.device) if want_recon else None
+        losses = torch.empty(3, dtype=torch.float32, device=self.device)
+        first = self.samples_seen
+        if flags & _lib.F_PHILOX:
+            self.samples_seen += B
+        check(lib.veex_net_forward(self._h, ptr(self.params), ptr(self.state), ptr(x), ptr(e), B, flags,
+                                   self.philox_seed, first, ptr(ws), ws.numel(), ptr(recon), ptr(losses),
+                                   ptr(self.metrics) if accumulate_metrics else None, _lib.current_stream()),
+              "net_forward")
+        return recon, losses
+
+    def train_fwd_bwd(self, x, eps=None, accumulate_metrics=True, first_sample: Optional[int] = None):
+        """Forward + loss + every gradient (VAE.train_step up to tape.gradient).  The three loss
+        scalars land in grads[-4:-1]."""
+        x = self._x(x)
+        B = x.shape[0]
+        ws = self.workspace(B)
+        e, flags = self._eps_args(eps, B)
+        if first_sample is None:
+            first_sample = self.samples_seen
+            if flags & _lib.F_PHILOX:
+                self.samples_seen += B
+        losses = self.grads[self.n_params:self.n_params + 3]
+        check(lib.veex_net_train_fwd_bwd(self._h, ptr(self.params), ptr(self.state), ptr(x), ptr(e), B, flags,
+                                         self.philox_seed, first_sample, ptr(ws), ws.numel(), ptr(self.grads),
+                                         ptr(losses), ptr(self.metrics) if accumulate_metrics else None,
+                                         _lib.current_stream()), "net_train_fwd_bwd")
+        return losses
+
+    def adam_step(self, lr: float, grad_scale: float = 1.0):
+        """optimizer.apply_gradients (models.py:169) with keras legacy Adam."""
+        check(lib.veex_adam(ptr(self.params), ptr(self.grads), ptr(self.adam_m), ptr(self.adam_v), self.n_params,
+                            ptr(self.adam_step_count), ptr(self.adam_alpha), float(lr), float(grad_scale),
+                            ADAM_B1, ADAM_B2, ADAM_EPS, _lib.current_stream()), "adam")
+
+    def attribute(self, x, units: Iterable[int], grad_x_input: bool = False) -> torch.Tensor:
+        """Saliency maps d z_mean[:, j] / d x, shape (len(units), B, 40, 40)."""
+        x = self._x(x)
+        B = x.shape[0]
+        units = [int(u) for u in units]
+        ws = self.workspace(B)
+        out = torch.empty(len(units), B, 40, 40, dtype=torch.float32, device=self.device)
+        arr = (C.c_int * len(units))(*units)
+        check(lib.veex_net_attribute(self._h, ptr(self.params), ptr(self.state), ptr(x), B, arr, len(units),
+                                     1 if grad_x_input else 0, ptr(ws), ws.numel(), ptr(out),
+                                     _lib.current_stream()), "net_attribute")
+        return out
