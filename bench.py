@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- VAE train samples/s on synthetic EEG topomaps (BASELINE.json metric, config[1]).
+
+One step = one VAE.train_step (forward + ELBO + all gradients [+ RCCL all-reduce] + TF-form
+Adam) over one batch of 512 (local) 40x40 topomaps that already sit in HBM.
+
+  python bench.py --gpus 1 --steps 50 --warmup 10
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the roofline arithmetic.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LATENT = 28
+LOCAL_BATCH = 512
+N_TRAIN = 100_000          # config[1]: 100k synthetic topomaps
+LR = 1e-5
+
+# algorithmic work (SURVEY 8d / BASELINE.md section 2)
+FWD_MACS = 82_526_496
+TRAIN_MACS = 247_356_704
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def synth(n, seed=1234):
+    """SURVEY 8d generator: coarse 8x8 normal field -> cubic zoom -> disc mask -> global min-max."""
+    from scipy.ndimage import zoom
+    rng = np.random.default_rng(seed)
+    out = np.empty((n, 40, 40, 1), dtype=np.float32)
+    yy, xx = np.mgrid[0:40, 0:40]
+    disc = (((yy - 19.5) ** 2 + (xx - 19.5) ** 2) <= 19.5 ** 2).astype(np.float32)
+    chunk = 10000
+    for s in range(0, n, chunk):
+        m = min(chunk, n - s)
+        coarse = rng.standard_normal((m, 8, 8))
+        fine = zoom(coarse, (1, 5, 5), order=3).astype(np.float32) * disc[None]
+        out[s:s + m, :, :, 0] = fine
+    lo, hi = out.min(), out.max()
+    out -= lo
+    out /= (hi - lo)
+    return out
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """config[0] on the host cores: the torch-CPU restatement (oracle/torch_ref.py, fp32, oneDNN)
+    of the reference train step, batch 64 -- kind 'port' (TensorFlow is not installable here)."""
+    import torch
+    from oracle import torch_ref, vae_oracle as vo
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    p = vo.init_params(LATENT, "vae", seed=42)
+    x = synth(1000, seed=99)
+    tr = torch_ref.TorchTrainer(p, LR, "vae", torch.float32)
+    tr.train_step(x[:64])            # warm-up
+    n_done, t0 = 0, time.perf_counter()
+    i = 0
+    while True:
+        xb = x[(i * 64) % 960:(i * 64) % 960 + 64]
+        tr.train_step(xb)
+        n_done += xb.shape[0]
+        i += 1
+        if time.perf_counter() - t0 > seconds_budget or i >= 64:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n_done / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{i} train steps of batch 64 (config[0] shape, 1k synthetic maps) in {dt:.1f}s, torch-CPU fp32 restatement"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=LOCAL_BATCH, help="local batch per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    from vae_eeg_xai_amd.net import Net
+    from vae_eeg_xai_amd import roofline as rl
+
+    B = args.batch
+    net = Net(LATENT, "vae")
+    net.init_weights(seed=42)                      # same weights on every rank
+    # weak scaling: every rank holds its own shard of the synthetic set (N_TRAIN / world maps)
+    n_local = max(B, (N_TRAIN // world) // B * B)
+    x_all = torch.from_numpy(synth(n_local, seed=1234 + rank)).cuda()
+    nb = n_local // B
+
+    def step(i):
+        xb = x_all[(i % nb) * B:(i % nb + 1) * B]
+        # Philox epsilon keyed by the global sample index -> independent of the world size
+        net.train_fwd_bwd(xb, None, first_sample=(i * world + rank) * B)
+        if world > 1:
+            dist.all_reduce(net.grads)             # one RCCL all-reduce: grads + 3 loss scalars
+        net.adam_step(LR, 1.0 / world)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(net.grads[net.n_params].item()) / world
+
+    if rank == 0:
+        sps = args.steps * B * world / dt
+        out = {
+            "metric": "VAE train samples/sec", "value": sps, "unit": "samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: models.py VAE train_step, 100k synthetic 40x40 topomaps, "
+                                   f"batch {B}/GPU, latent 28, Adam lr 1e-5, fp32 (exact-f32 MFMA)",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": loss},
+            "train_tflops": sps * TRAIN_MACS * 2 / 1e12,
+            "frac_f32_mfma_peak": sps * TRAIN_MACS * 2 / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
+        }
+        if not args.no_roofline:
+            out["roofline"] = rl.dominant_kernel_roofline(net, B)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -250,11 +250,14 @@ def encoder_fwd(p, x, variant="vae"):
         pre = conv2d_fwd(h, p[f"enc.{name}.kernel"], p[f"enc.{name}.bias"], s, pad)
         a = np.maximum(pre, 0)
         h = bn_fwd(a, p[f"enc.{name}.gamma"], p[f"enc.{name}.beta"], p[f"enc.{name}.mean"], p[f"enc.{name}.var"])
+        c[f"enc.{name}.pre"] = pre
         c[f"enc.{name}.a"] = a
         c[f"enc.{name}.y"] = h
     flat = h.reshape(h.shape[0], -1)                              # Flatten (h,w,c) models.py:237
     c["enc.flat"] = flat
-    d = np.maximum(flat @ p["enc.dense.kernel"] + p["enc.dense.bias"], 0)   # Dense relu
+    dpre_ = flat @ p["enc.dense.kernel"] + p["enc.dense.bias"]
+    d = np.maximum(dpre_, 0)   # Dense relu
+    c["enc.dense.pre"] = dpre_
     c["enc.dense.a"] = d
     if variant == "vae":
         c["z_mean"] = d @ p["enc.z_mean.kernel"] + p["enc.z_mean.bias"]
@@ -271,7 +274,9 @@ def decoder_fwd(p, z, c=None):
     """Decoder.call (models.py:303-312): Dense relu -> BN -> reshape (4,4,256) -> 5x[deconv relu BN] -> deconv6."""
     c = {} if c is None else c
     c["z"] = z
-    a = np.maximum(z @ p["dec.dense.kernel"] + p["dec.dense.bias"], 0)
+    pre = z @ p["dec.dense.kernel"] + p["dec.dense.bias"]
+    a = np.maximum(pre, 0)
+    c["dec.dense.pre"] = pre
     c["dec.dense.a"] = a
     h = bn_fwd(a, p["dec.dense.gamma"], p["dec.dense.beta"], p["dec.dense.mean"], p["dec.dense.var"])
     h = h.reshape(-1, 4, 4, 256)
@@ -283,6 +288,7 @@ def decoder_fwd(p, z, c=None):
             c["recon"] = sigmoid(pre)
             break
         a = np.maximum(pre, 0)
+        c[f"dec.{name}.pre"] = pre
         c[f"dec.{name}.a"] = a
         h = bn_fwd(a, p[f"dec.{name}.gamma"], p[f"dec.{name}.beta"], p[f"dec.{name}.mean"], p[f"dec.{name}.var"])
     return c
@@ -313,9 +319,18 @@ def forward(p, x, eps=None, variant="vae"):
     return c
 
 
-def backward(p, c, variant="vae"):
-    """Gradients of ``total`` wrt every trainable tensor (tape.gradient, models.py:166)."""
+def backward(p, c, variant="vae", masks=None):
+    """Gradients of ``total`` wrt every trainable tensor (tape.gradient, models.py:166).
+
+    ``masks`` (optional) maps "<layer>" (e.g. "dec.deconv3", "enc.dense") to a boolean ReLU
+    mask that replaces ``a > 0``: a pre-activation within fp32 rounding of 0 has an ambiguous
+    sub-gradient, so parity tests evaluate the oracle at the device's ReLU decisions after
+    checking that every disagreement sits at such a kink."""
     g = {}
+    masks = masks or {}
+
+    def on(layer, a):
+        return masks[layer] if layer in masks else (a > 0)
     x = c["x"]
     B = x.shape[0]
     dh = (sigmoid(c["logits"]) - x) / B                           # d rec / d logits (SURVEY A.4)
@@ -326,7 +341,7 @@ def backward(p, c, variant="vae"):
             a = c[f"dec.{name}.a"]
             da, g[f"dec.{name}.gamma"], g[f"dec.{name}.beta"] = bn_bwd(
                 a, p[f"dec.{name}.gamma"], p[f"dec.{name}.mean"], p[f"dec.{name}.var"], dh)
-            dh = da * (a > 0)
+            dh = da * on(f"dec.{name}", a)
         g[f"dpre.dec.{name}"] = dh
         dh, g[f"dec.{name}.kernel"], g[f"dec.{name}.bias"] = deconv2d_bwd(
             c[f"dec.{name}.in"], p[f"dec.{name}.kernel"], dh, s, pad)
@@ -334,7 +349,8 @@ def backward(p, c, variant="vae"):
     a = c["dec.dense.a"]
     da, g["dec.dense.gamma"], g["dec.dense.beta"] = bn_bwd(
         a, p["dec.dense.gamma"], p["dec.dense.mean"], p["dec.dense.var"], dh)
-    dpre = da * (a > 0)
+    dpre = da * on("dec.dense", a)
+    g["dpre.dec.dense"] = dpre
     g["dec.dense.kernel"] = c["z"].T @ dpre
     g["dec.dense.bias"] = dpre.sum(0)
     dz = dpre @ p["dec.dense.kernel"].T
@@ -352,7 +368,8 @@ def backward(p, c, variant="vae"):
         dd = dmu @ p["enc.z_mean.kernel"].T + dlv @ p["enc.z_log_var.kernel"].T
     else:
         dd = dz
-    dpre = dd * (d > 0)
+    dpre = dd * on("enc.dense", d)
+    g["dpre.enc.dense"] = dpre
     g["enc.dense.kernel"] = c["enc.flat"].T @ dpre
     g["enc.dense.bias"] = dpre.sum(0)
     dh = (dpre @ p["enc.dense.kernel"].T).reshape(B, 5, 5, 256)
@@ -360,7 +377,7 @@ def backward(p, c, variant="vae"):
         a = c[f"enc.{name}.a"]
         da, g[f"enc.{name}.gamma"], g[f"enc.{name}.beta"] = bn_bwd(
             a, p[f"enc.{name}.gamma"], p[f"enc.{name}.mean"], p[f"enc.{name}.var"], dh)
-        dpre = da * (a > 0)
+        dpre = da * on(f"enc.{name}", a)
         g[f"dpre.enc.{name}"] = dpre
         xin = c["x"] if name == "conv1" else c[f"enc.conv{int(name[-1]) - 1}.y"]
         dh, g[f"enc.{name}.kernel"], g[f"enc.{name}.bias"] = conv2d_bwd(

@@ -15,11 +15,22 @@ def run(variant, L, B, jitter=0.1):
     x = vo.synth_topomaps(B, 5)
     eps = np.random.default_rng(7).standard_normal((B, L)).astype(np.float32) if variant == "vae" else None
     c = vo.forward(p, x, eps, variant)
-    g = vo.backward(p, c, variant)
     net = Net(L, variant)
     net.set_weights_dict(p)
     losses = net.train_fwd_bwd(x, eps)
     torch.cuda.synchronize()
+    # ReLU decisions of the device; disagreements must sit at fp32-rounding kinks
+    masks = {}
+    layers = ["enc.conv1", "enc.conv2", "enc.conv3", "enc.dense", "dec.dense"] + [f"dec.deconv{i}" for i in range(1, 6)]
+    for ln in layers:
+        ref_pre = c[ln + ".pre"]
+        got = net.ws_region(B, "act." + ln).cpu().numpy().reshape(ref_pre.shape)
+        m = got > 0
+        dis = m != (ref_pre > 0)
+        if dis.any():
+            print(f"  mask {ln}: {int(dis.sum())} disagreements, max |pre_ref| there = {np.abs(ref_pre[dis]).max():.3e} (scale {np.abs(ref_pre).max():.3e})")
+        masks[ln] = m
+    g = vo.backward(p, c, variant, masks)
     bad = 0
     def chk(name, got, ref, tol=2e-5):
         nonlocal bad
