@@ -36,8 +36,95 @@ __device__ __forceinline__ float4 ld4(const float* ptr, bool ok, int nvalid, boo
   return v;
 }
 
+// Shared epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
+                                            const int* s_off, float* As, int m0, int n0) {
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MT = WTM / 32, NT = WTN / 32;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lh = lane >> 5, l31 = lane & 31;
+  (void)m0;
+  // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float cs1[NT], cs2[NT], cs3[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { cs1[j] = 0.f; cs2[j] = 0.f; cs3[j] = 0.f; }
+
+  float* outp = p.Out;
+  if (p.epi == VEEX_EPI_RAW) outp += (long long)blockIdx.z * p.slab_stride;
+
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + wn * WTN + j * 32 + l31;
+    const bool colok = col < p.Cout;
+    float bia = 0.f, esc = 1.f;
+    if (colok) {
+      if (p.epi == VEEX_EPI_FWD && p.bias != nullptr) bia = p.bias[col];
+      if (p.epi == VEEX_EPI_BWD && p.e_scale != nullptr) esc = p.e_scale[col & p.epi_cmask];
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int off = s_off[rl];
+        if (off < 0 || !colok) continue;
+        const long long addr = (long long)off * p.Cout + col;
+        float v = acc[i][j][r];
+        if (p.epi == VEEX_EPI_FWD) {
+          v += bia;
+          if (p.relu) v = fmaxf(v, 0.f);
+          outp[addr] = v;
+        } else if (p.epi == VEEX_EPI_BWD) {
+          const float a = p.aux[addr];
+          const bool on = (!p.relu) || (a > 0.f);
+          cs1[j] += v;
+          cs2[j] = fmaf(v, a, cs2[j]);
+          cs3[j] += on ? v : 0.f;
+          outp[addr] = on ? v * esc : 0.f;
+        } else {
+          outp[addr] = v;
+        }
+      }
+    }
+  }
+
+  if (p.epi == VEEX_EPI_BWD && p.partials != nullptr) {
+    // column sums: lane halves -> waves sharing the columns (wm) -> one row of the partial slab
+    float* s_red = As;   // [WM][BN][3]; safe: every wave passed the loop's last barrier
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      cs1[j] += __shfl_xor(cs1[j], 32);
+      cs2[j] += __shfl_xor(cs2[j], 32);
+      cs3[j] += __shfl_xor(cs3[j], 32);
+      if (lh == 0) {
+        const int cl = wn * WTN + j * 32 + l31;
+        s_red[(wm * BN + cl) * 3 + 0] = cs1[j];
+        s_red[(wm * BN + cl) * 3 + 1] = cs2[j];
+        s_red[(wm * BN + cl) * 3 + 2] = cs3[j];
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.Cout) {
+      float t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        t1 += s_red[(w * BN + tid) * 3 + 0];
+        t2 += s_red[(w * BN + tid) * 3 + 1];
+        t3 += s_red[(w * BN + tid) * 3 + 2];
+      }
+      float* pp = p.partials + (long long)blockIdx.x * 3 * p.Cout + n0 + tid;
+      pp[0] = t1;
+      pp[p.Cout] = t2;
+      pp[2 * p.Cout] = t3;
+    }
+  }
+}
+
 template <int BM, int BN, int WM, int WN, bool MODE1>
-__global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
+__global__ __launch_bounds__(256) void gather_gemm_generic_kernel(const GGParams p) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 32, NT = WTN / 32;
   constexpr int APASS = BM / 64;
@@ -246,81 +333,256 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue ----
-  // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  float cs1[NT], cs2[NT], cs3[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) { cs1[j] = 0.f; cs2[j] = 0.f; cs3[j] = 0.f; }
+  gg_epilogue<BM, BN, WM, WN>(p, acc, s_off, As, m0, n0);
+}
 
-  float* outp = p.Out;
-  if (p.epi == VEEX_EPI_RAW) outp += (long long)blockIdx.z * p.slab_stride;
 
+// ---------------------------------------------------------------------------
+// Fast path (all vector dims % 4 == 0, every operand < 4 GiB).  Differences to the generic kernel:
+//  * every global access is a 16-byte raw buffer load whose offset is forced out of range for
+//    padding pixels / K tails / rows past M, so the hardware returns zeros: no branch around any
+//    load, the K loop is ONE basic block and hipcc interleaves loads, LDS traffic and the 64-cycle
+//    f32 MFMAs freely;
+//  * per-row addressing is (row base) + (wave-uniform tap delta) + (chunk offset); validity of a
+//    (row, tap) pair is one bit of a per-row mask computed once before the loop.
+// AFF: 0 none, 1 per-channel producer BatchNorm, 2 BatchNorm over the flattened (h,w,c) vector.
+// ---------------------------------------------------------------------------
+typedef unsigned int v4u __attribute__((__vector_size__(16)));
+typedef float v4f __attribute__((__vector_size__(16)));
+#define VEEX_OOB 0xFFFFFF00u
+
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  const v4f f = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+  return make_float4(f[0], f[1], f[2], f[3]);
+}
+
+template <int BM, int BN, int WM, int WN, bool MODE1, int AFF>
+__global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MT = WTM / 32, NT = WTN / 32;
+  constexpr int APASS = BM / 64;
+  constexpr int A_ELEMS = BM * VEEX_LDK;
+  constexpr int LDN = BN + 4;
+  constexpr int B_ELEMS = MODE1 ? BN * VEEX_LDK : VEEX_BK * LDN;
+  constexpr int BPASS = MODE1 ? BN / 64 : (VEEX_BK * BN / 4) / 256;
+  constexpr int QN = BN / 4;
+  constexpr int RPP = 256 / QN;
+  static_assert(WM * WN == 4, "4 waves");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * A_ELEMS;
+  int* s_off = reinterpret_cast<int*>(Bs + 2 * B_ELEMS);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lh = lane >> 5, l31 = lane & 31;
+
+  int tile = blockIdx.x, ph = 0;
+  if (p.nphase == 4) {
+    while (ph < 3 && tile >= p.tile_prefix[ph + 1]) ++ph;
+  }
+  const int py = ph >> 1, px = ph & 1;
+  const int Hp = p.Hp[py], Wp = p.Wp[px];
+  const int ostep = (p.nphase == 4) ? 2 : 1;
+  const int oy0 = p.o0[py], ox0 = p.o0[px];
+  const int Mph = p.Nb * Hp * Wp;
+  const int m0 = (tile - p.tile_prefix[ph]) * BM;
+  const int n0 = blockIdx.y * BN;
+
+  int kys = 0, kxs = 0, kstep = 1, nky = p.kh, nkx = p.kw;
+  if (p.nphase == 4) {
+    kys = py; kxs = px; kstep = 2;
+    nky = (p.kh - py + 1) >> 1;
+    nkx = (p.kw - px + 1) >> 1;
+  }
+  const int cpt = (p.Cin + VEEX_BK - 1) / VEEX_BK;
+  const int nchunks = nky * nkx * cpt;
+  const int c_begin = blockIdx.z * p.chunks_per_split;
+  const int c_end = min(nchunks, c_begin + p.chunks_per_split);
+  const int HWp = Hp * Wp;
+
+  if (tid < BM) {
+    int m = m0 + tid, off = -1;
+    if (m < Mph) {
+      int n = m / HWp, rem = m - n * HWp;
+      int j = rem / Wp, i = rem - j * Wp;
+      off = (n * p.Hout + ostep * j + oy0) * p.Wout + ostep * i + ox0;
+    }
+    s_off[tid] = off;
+  }
+
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.A), 0, (int)((unsigned)p.Nb * p.Hin * p.Win * p.Cin * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.W), 0, (int)((unsigned)p.kh * p.kw * p.Cin * p.Cout * 4u), 0x00020000);
+  const unsigned aff_bytes = (AFF != 0) ? (unsigned)(p.aff_mask + 1) * 4u : 0u;
+  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(AFF != 0 ? p.a_scale : p.A), 0, (int)aff_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(AFF != 0 ? p.a_shift : p.A), 0, (int)aff_bytes, 0x00020000);
+
+  // ---- per-row state of the A loader: rows (tid>>2)+64*i, k-quad (tid&3) ----
+  const int q = tid & 3, lr = tid >> 2;
+  int a_rowbase[APASS];        // byte offset of (row pixel at phase tap (0,0), channel 4q); may be "virtual"
+  int a_nbase[APASS];          // byte offset of the sample (for AFF==2)
+  unsigned a_mask[APASS];      // bit t set <=> tap index t of this phase reads an in-bounds pixel
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int col = n0 + wn * WTN + j * 32 + l31;
-    const bool colok = col < p.Cout;
-    float bia = 0.f, esc = 1.f;
-    if (colok) {
-      if (p.epi == VEEX_EPI_FWD && p.bias != nullptr) bia = p.bias[col];
-      if (p.epi == VEEX_EPI_BWD && p.e_scale != nullptr) esc = p.e_scale[col & p.epi_cmask];
+  for (int i = 0; i < APASS; ++i) {
+    const int m = m0 + lr + 64 * i;
+    a_rowbase[i] = 0; a_mask[i] = 0u; a_nbase[i] = 0;
+    if (m < Mph) {
+      const int n = m / HWp, rem = m - n * HWp;
+      const int j = rem / Wp, ii = rem - j * Wp;
+      const int oy = ostep * j + oy0, ox = ostep * ii + ox0;
+      int by, bx;   // input pixel read by phase tap (0,0)
+      if (MODE1) { by = (oy + p.pb - kys) >> (p.stride - 1); bx = (ox + p.pb - kxs) >> (p.stride - 1); }
+      else       { by = p.stride * oy - p.pb; bx = p.stride * ox - p.pb; }
+      a_nbase[i] = n * p.Hin * p.Win * p.Cin * 4;
+      a_rowbase[i] = a_nbase[i] + ((by * p.Win + bx) * p.Cin + 4 * q) * 4;
+      unsigned mk = 0u;
+      for (int ia = 0; ia < nky; ++ia)
+        for (int ib = 0; ib < nkx; ++ib) {
+          const int iy = MODE1 ? by - ia : by + ia, ix = MODE1 ? bx - ib : bx + ib;
+          bool ok = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+          if (MODE1) ok = ok && (oy + p.pb - (kys + kstep * ia)) >= 0 && (ox + p.pb - (kxs + kstep * ib)) >= 0;
+          if (ok) mk |= 1u << (ia * nkx + ib);
+        }
+      a_mask[i] = mk;
+    }
+  }
+  // B loader state
+  const int nq = tid % QN, kr = tid / QN;
+  int b_rowbase[BPASS];
+  bool b_ok[BPASS];
+#pragma unroll
+  for (int i = 0; i < BPASS; ++i) {
+    if (MODE1) {   // [tap][Cout][Cin]: row n, quad q along Cin
+      const int n = n0 + lr + 64 * i;
+      b_ok[i] = n < p.Cout;
+      b_rowbase[i] = (n * p.Cin + 4 * q) * 4;
+    } else {       // [tap][Cin][Cout]: row k, quad nq along Cout
+      const int n = n0 + 4 * nq;
+      b_ok[i] = n < p.Cout;
+      b_rowbase[i] = ((kr + RPP * i) * p.Cout + n) * 4;
+    }
+  }
+  const int tap_bytes = p.Cin * p.Cout * 4;
+
+  float4 ra[APASS], rb[BPASS], rsc[AFF == 2 ? APASS : 1], rsh[AFF == 2 ? APASS : 1];
+  bool rok[APASS];
+
+  auto load_chunk = [&](int c, bool cvalid) {
+    const int tapi = c / cpt;
+    const int cc = c - tapi * cpt;
+    const int ia = tapi / nkx, ib = tapi - ia * nkx;
+    const int tap = (kys + kstep * ia) * p.kw + (kxs + kstep * ib);
+    const int ci0 = cc * VEEX_BK;
+    const int dpix = ia * p.Win + ib;
+    const int delta = (MODE1 ? -dpix : dpix) * p.Cin * 4 + ci0 * 4;
+    const bool kq = cvalid && (ci0 + 4 * q < p.Cin);
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      const bool ok = kq && ((a_mask[i] >> tapi) & 1u);
+      const unsigned off = ok ? (unsigned)(a_rowbase[i] + delta) : VEEX_OOB;
+      ra[i] = bload4(rA, off);
+      rok[i] = ok;
+      if (AFF == 2) {
+        const unsigned ao = ok ? (unsigned)(a_rowbase[i] + delta - a_nbase[i]) : VEEX_OOB;
+        rsc[i] = bload4(rS, ao);
+        rsh[i] = bload4(rH, ao);
+      }
+    }
+    if (AFF == 1) {
+      const unsigned ao = kq ? (unsigned)(((ci0 + 4 * q) & p.aff_mask) * 4) : VEEX_OOB;
+      rsc[0] = bload4(rS, ao);
+      rsh[0] = bload4(rH, ao);
     }
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    for (int i = 0; i < BPASS; ++i) {
+      bool ok;
+      unsigned off;
+      if (MODE1) {
+        ok = kq && b_ok[i];
+        off = (unsigned)(tap * tap_bytes + b_rowbase[i] + ci0 * 4);
+      } else {
+        ok = cvalid && b_ok[i] && (ci0 + kr + RPP * i < p.Cin);
+        off = (unsigned)(tap * tap_bytes + ci0 * p.Cout * 4 + b_rowbase[i]);
+      }
+      rb[i] = bload4(rW, ok ? off : VEEX_OOB);
+    }
+  };
+
+  auto store_chunk = [&](int buf) {
+    float* as = As + buf * A_ELEMS;
+    float* bs = Bs + buf * B_ELEMS;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rl = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int off = s_off[rl];
-        if (off < 0 || !colok) continue;
-        const long long addr = (long long)off * p.Cout + col;
-        float v = acc[i][j][r];
-        if (p.epi == VEEX_EPI_FWD) {
-          v += bia;
-          if (p.relu) v = fmaxf(v, 0.f);
-          outp[addr] = v;
-        } else if (p.epi == VEEX_EPI_BWD) {
-          const float a = p.aux[addr];
-          const bool on = (!p.relu) || (a > 0.f);
-          cs1[j] += v;
-          cs2[j] = fmaf(v, a, cs2[j]);
-          cs3[j] += on ? v : 0.f;
-          outp[addr] = on ? v * esc : 0.f;
+    for (int i = 0; i < APASS; ++i) {
+      float4 v = ra[i];
+      if (AFF != 0) {
+        const float4 sc = rsc[AFF == 2 ? i : 0], sh = rsh[AFF == 2 ? i : 0];
+        // padding pixels must stay 0 (the shift only applies to real pixels)
+        v.x = rok[i] ? fmaf(v.x, sc.x, sh.x) : 0.f; v.y = rok[i] ? fmaf(v.y, sc.y, sh.y) : 0.f;
+        v.z = rok[i] ? fmaf(v.z, sc.z, sh.z) : 0.f; v.w = rok[i] ? fmaf(v.w, sc.w, sh.w) : 0.f;
+      }
+      *reinterpret_cast<float4*>(as + (lr + 64 * i) * VEEX_LDK + 4 * q) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+      if (MODE1) *reinterpret_cast<float4*>(bs + (lr + 64 * i) * VEEX_LDK + 4 * q) = rb[i];
+      else       *reinterpret_cast<float4*>(bs + (kr + RPP * i) * LDN + 4 * nq) = rb[i];
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_chunk(c_begin, c_begin < c_end);
+  store_chunk(0);
+  __syncthreads();
+
+  for (int c = c_begin; c < c_end; ++c) {
+    const int cur = (c - c_begin) & 1;
+    load_chunk(c + 1, c + 1 < c_end);   // past the end: every offset out of range -> zeros, never read
+    const float* as = As + cur * A_ELEMS + (wm * WTM + l31) * VEEX_LDK + 8 * lh;
+    const float* bs = MODE1 ? (Bs + cur * B_ELEMS + (wn * WTN + l31) * VEEX_LDK + 8 * lh)
+                            : (Bs + cur * B_ELEMS + (8 * lh) * LDN + wn * WTN + l31);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float av[MT][4], bv[NT][4];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const float4 t = *reinterpret_cast<const float4*>(as + i * 32 * VEEX_LDK + 4 * half);
+        av[i][0] = t.x; av[i][1] = t.y; av[i][2] = t.z; av[i][3] = t.w;
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (MODE1) {
+          const float4 t = *reinterpret_cast<const float4*>(bs + j * 32 * VEEX_LDK + 4 * half);
+          bv[j][0] = t.x; bv[j][1] = t.y; bv[j][2] = t.z; bv[j][3] = t.w;
         } else {
-          outp[addr] = v;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) bv[j][kk] = bs[(4 * half + kk) * LDN + j * 32];
         }
       }
-    }
-  }
-
-  if (p.epi == VEEX_EPI_BWD && p.partials != nullptr) {
-    // column sums: lane halves -> waves sharing the columns (wm) -> one row of the partial slab
-    float* s_red = As;   // [WM][BN][3]; safe: every wave passed the loop's last barrier
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      cs1[j] += __shfl_xor(cs1[j], 32);
-      cs2[j] += __shfl_xor(cs2[j], 32);
-      cs3[j] += __shfl_xor(cs3[j], 32);
-      if (lh == 0) {
-        const int cl = wn * WTN + j * 32 + l31;
-        s_red[(wm * BN + cl) * 3 + 0] = cs1[j];
-        s_red[(wm * BN + cl) * 3 + 1] = cs2[j];
-        s_red[(wm * BN + cl) * 3 + 2] = cs3[j];
-      }
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][kk], bv[j][kk], acc[i][j], 0, 0, 0);
     }
+    store_chunk(cur ^ 1);
     __syncthreads();
-    if (tid < BN && n0 + tid < p.Cout) {
-      float t1 = 0.f, t2 = 0.f, t3 = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) {
-        t1 += s_red[(w * BN + tid) * 3 + 0];
-        t2 += s_red[(w * BN + tid) * 3 + 1];
-        t3 += s_red[(w * BN + tid) * 3 + 2];
-      }
-      float* pp = p.partials + (long long)blockIdx.x * 3 * p.Cout + n0 + tid;
-      pp[0] = t1;
-      pp[p.Cout] = t2;
-      pp[2 * p.Cout] = t3;
-    }
   }
+  gg_epilogue<BM, BN, WM, WN>(p, acc, s_off, As, m0, n0);
 }
 
 // ---------------------------------------------------------------------------
@@ -364,17 +626,33 @@ int veex_gg_m_tiles(GGParams& p) {
   return t;
 }
 
-template <int BM, int BN, int WM, int WN>
-static int gg_launch_cfg(const GGParams& p, int mtiles, hipStream_t st) {
+template <int BM, int BN, bool MODE1>
+static constexpr size_t gg_lds_bytes() {
+  return (2 * BM * VEEX_LDK + 2 * (MODE1 ? BN * VEEX_LDK : VEEX_BK * (BN + 4))) * sizeof(float) + BM * sizeof(int);
+}
+
+template <int BM, int BN, bool MODE1>
+static int gg_launch_fast(const GGParams& p, dim3 grid, hipStream_t st) {
+  constexpr size_t lds = gg_lds_bytes<BM, BN, MODE1>();
+  const int aff = (p.a_scale == nullptr) ? 0 : (p.aff_spatial ? 2 : 1);
+  if (aff == 0) hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 2, 2, MODE1, 0>), grid, dim3(256), lds, st, p);
+  else if (aff == 1) hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 2, 2, MODE1, 1>), grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 2, 2, MODE1, 2>), grid, dim3(256), lds, st, p);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int BM, int BN>
+static int gg_launch_cfg(const GGParams& p, int mtiles, bool fast, hipStream_t st) {
   const int ntiles = (p.Cout + BN - 1) / BN;
   dim3 grid(mtiles, ntiles, p.nsplit);
-  if (p.mode == 1) {
-    constexpr size_t lds = (2 * BM * VEEX_LDK + 2 * BN * VEEX_LDK) * sizeof(float) + BM * sizeof(int);
-    hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, WM, WN, true>), grid, dim3(256), lds, st, p);
-  } else {
-    constexpr size_t lds = (2 * BM * VEEX_LDK + 2 * VEEX_BK * (BN + 4)) * sizeof(float) + BM * sizeof(int);
-    hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, WM, WN, false>), grid, dim3(256), lds, st, p);
-  }
+  if (fast) return (p.mode == 1) ? gg_launch_fast<BM, BN, true>(p, grid, st) : gg_launch_fast<BM, BN, false>(p, grid, st);
+  constexpr size_t lds1 = gg_lds_bytes<BM, BN, true>();
+  constexpr size_t lds0 = gg_lds_bytes<BM, BN, false>();
+  if (p.mode == 1)
+    hipLaunchKernelGGL((gather_gemm_generic_kernel<BM, BN, 2, 2, true>), grid, dim3(256), lds1, st, p);
+  else
+    hipLaunchKernelGGL((gather_gemm_generic_kernel<BM, BN, 2, 2, false>), grid, dim3(256), lds0, st, p);
   VEEX_CHECK_LAUNCH();
   return 0;
 }
@@ -399,7 +677,21 @@ int veex_launch_gather_gemm(const GGParams& pin, hipStream_t st) {
   if (p.nsplit == 1) p.chunks_per_split = 1 << 30;
   const int bm = veex_gg_bm(p.Cout, Mtot);
   const int bn = gg_bn(p.Cout, bm);
-  if (bm == 128 && bn == 128) return gg_launch_cfg<128, 128, 2, 2>(p, mtiles, st);
-  if (bm == 128 && bn == 64) return gg_launch_cfg<128, 64, 2, 2>(p, mtiles, st);
-  return gg_launch_cfg<64, 64, 2, 2>(p, mtiles, st);
+  // fast path: 16-byte buffer loads everywhere, 32-bit byte offsets, tap-validity bit mask
+  const long long a_bytes = (long long)p.Nb * p.Hin * p.Win * p.Cin * 4;
+  const long long w_bytes = (long long)p.kh * p.kw * p.Cin * p.Cout * 4;
+  const bool vec_ok = (p.Cin % 4 == 0) && (p.mode == 1 || p.Cout % 4 == 0);
+  const bool fast = vec_ok && a_bytes < 0x7FFF0000LL && w_bytes < 0x7FFF0000LL && p.kh * p.kw <= 32 &&
+                    (p.a_scale == nullptr || !p.aff_spatial || (p.aff_mask + 1) == p.Hin * p.Win * p.Cin);
+  if (bm == 128 && bn == 128 && fast) return gg_launch_cfg<128, 128>(p, mtiles, true, st);
+  if (bm == 128 && bn == 64 && fast) return gg_launch_cfg<128, 64>(p, mtiles, true, st);
+  if (bm == 64 && fast) return gg_launch_cfg<64, 64>(p, mtiles, true, st);
+  // generic (scalar-capable) kernel is instantiated for the 64x64 tile only
+  if (bm != 64) {
+    // re-plan the phase tables for 64-row tiles is not possible here (callers sized partials by
+    // veex_gg_m_tiles), so large-M problems must satisfy the fast-path constraints
+    veex_set_error("gather_gemm: M >= 4096 requires channel counts %% 4 == 0 and operands < 2 GiB");
+    return -1;
+  }
+  return gg_launch_cfg<64, 64>(p, mtiles, false, st);
 }
