@@ -138,8 +138,8 @@ int veex_slab_sum(const float* slab, int nsplit, long long stride, long long n, 
 
 /* keras.optimizers.legacy.Adam (train.py:9,137,193): p -= alpha_t*m/(sqrt(v)+eps), alpha_t =
  * lr*sqrt(1-b2^t)/(1-b1^t); step[0] (device int) is incremented; gscale multiplies g (1/world). */
-int veex_adam(float* p, const float* g, float* m, float* v, long long n, int* step, float* alpha, float lr,
-              float gscale, float b1, float b2, float eps, veexStream_t s);
+int veex_adam(float* p, const float* g, float* m, float* v, long long n, int* step, float* alpha, double lr,
+              double gscale, double b1, double b2, double eps, veexStream_t s);
 
 /* ------------------------------------------------------------------------------------------
  * Network level: the whole Encoder / Decoder / VAE.train_step graph as one enqueue.

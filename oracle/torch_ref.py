@@ -106,7 +106,7 @@ def grads(params_np: dict, x_np, eps_np=None, variant="vae", dtype=torch.float64
     total, rec, kl, logits = losses(p, x, eps, variant)
     names = [k for k, t in p.items() if t.requires_grad]
     gs = torch.autograd.grad(total, [p[k] for k in names])
-    return float(total), float(rec), float(kl), {k: g.numpy() for k, g in zip(names, gs)}
+    return float(total.detach()), float(rec.detach()), float(kl.detach()), {k: g.numpy() for k, g in zip(names, gs)}
 
 
 def saliency(params_np, x_np, units, variant="vae", dtype=torch.float64, grad_x_input=False):

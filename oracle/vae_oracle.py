@@ -386,11 +386,16 @@ def backward(p, c, variant="vae", masks=None):
     return g
 
 
-def attribution(p, x, units, variant="vae", grad_x_input=False):
+def attribution(p, x, units, variant="vae", grad_x_input=False, masks=None):
     """Saliency d z_mean[:, j] / d x for each j in ``units`` (north_star item 3; no reference
     call site -- SURVEY 3.4).  For the AE variant the target is the bottleneck unit.
-    Returns (len(units), B, 40, 40, 1)."""
+    ``masks``: optional ReLU decisions, see ``backward``.  Returns (len(units), B, 40, 40, 1)."""
     x = np.asarray(x, dtype=np.float64)
+    masks = masks or {}
+
+    def on(layer, a):
+        return masks[layer] if layer in masks else (a > 0)
+
     c = encoder_fwd(p, x, variant)
     B = x.shape[0]
     out = []
@@ -398,15 +403,15 @@ def attribution(p, x, units, variant="vae", grad_x_input=False):
     for j in units:
         if variant == "vae":
             dd = np.tile(p["enc.z_mean.kernel"][:, j][None, :], (B, 1))
-            dpre = dd * (d > 0)
+            dpre = dd * on("enc.dense", d)
         else:
             dpre = np.zeros_like(d)
-            dpre[:, j] = (d[:, j] > 0)
+            dpre[:, j] = on("enc.dense", d)[:, j]
         dh = (dpre @ p["enc.dense.kernel"].T).reshape(B, 5, 5, 256)
         for name, cin, cout, k, s, pad in reversed(ENC_CONVS):
             a = c[f"enc.{name}.a"]
             da, _, _ = bn_bwd(a, p[f"enc.{name}.gamma"], p[f"enc.{name}.mean"], p[f"enc.{name}.var"], dh)
-            dpre = da * (a > 0)
+            dpre = da * on(f"enc.{name}", a)
             xin = c["x"] if name == "conv1" else c[f"enc.conv{int(name[-1]) - 1}.y"]
             dh, _, _ = conv2d_bwd(xin, p[f"enc.{name}.kernel"], dpre, s, pad)
         out.append(dh * x if grad_x_input else dh)

@@ -1,0 +1,248 @@
+"""GPU parity of the whole hot path against the float64 oracle, through the C-ABI (libveex.so)
+as bound by vae_eeg_xai_amd.net.Net.  Tolerance: 1e-5 relative to the tensor's max-abs
+(north_star: "within 1e-5 relative (fp32)")."""
+import numpy as np
+import pytest
+
+from oracle import vae_oracle as vo
+from util import RTOL, LAYERS, device_masks, golden_cases, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(variant, L):
+    from vae_eeg_xai_amd.net import Net
+    return Net(L, variant)
+
+
+def _case(variant, L, B, seed=3, jitter=0.1):
+    p = vo.init_params(L, variant, seed=seed, jitter=jitter)
+    x = vo.synth_topomaps(B, seed + 2)
+    eps = np.random.default_rng(seed + 4).standard_normal((B, L)).astype(np.float32) if variant == "vae" else None
+    return p, x, eps
+
+
+# edge cases: tiny batch, batch that is not a multiple of any tile (70), the plain autoencoder,
+# a latent size that forces the scalar (non-16-byte) kernels (L=2) and the largest swept latent (128)
+@pytest.mark.parametrize("variant,L,B", [("vae", 28, 4), ("vae", 28, 70), ("ae", 28, 6), ("vae", 2, 5),
+                                         ("vae", 128, 3), ("ae", 16, 1)])
+def test_train_step_forward_loss_and_every_gradient(variant, L, B):
+    import torch
+    p, x, eps = _case(variant, L, B)
+    c = vo.forward(p, x, eps, variant)
+    net = _net(variant, L)
+    net.set_weights_dict(p)
+    losses = net.train_fwd_bwd(x, eps).cpu().numpy()
+    torch.cuda.synchronize()
+
+    def ws(name, shape):
+        return net.ws_region(B, name).cpu().numpy().reshape(shape)
+
+    # forward
+    for ln in LAYERS:
+        ref = c[ln + ".a"]
+        assert rel_err(ws("act." + ln, ref.shape), ref) < RTOL, ln
+    if variant == "vae":
+        mulv = ws("mulv", (B, 2 * L))
+        assert rel_err(mulv[:, :L], c["z_mean"]) < RTOL
+        assert rel_err(mulv[:, L:], c["z_log_var"]) < RTOL
+        assert rel_err(ws("z", (B, L)), c["z"]) < RTOL
+    assert abs(losses[0] - c["total"]) < RTOL * abs(c["total"])
+    assert abs(losses[1] - c["rec_loss"]) < RTOL * abs(c["rec_loss"])
+    if variant == "vae":
+        assert abs(losses[2] - c["kl_loss"]) < RTOL * max(abs(c["kl_loss"]), 1.0)
+    # backward, evaluated at the device's ReLU decisions (disagreements only at fp32 kinks)
+    g = vo.backward(p, c, variant, device_masks(net, B, c))
+    assert rel_err(ws("dlogit", (B, 40, 40, 1)), g["dlogits"]) < RTOL
+    for i in range(5, 0, -1):
+        ref = g[f"dpre.dec.deconv{i}"]
+        assert rel_err(ws(f"dpre.dec.deconv{i}", ref.shape), ref) < RTOL, i
+    assert rel_err(ws("dz", (B, L)), g["dz"]) < RTOL
+    for nm in ("conv3", "conv2", "conv1"):
+        ref = g[f"dpre.enc.{nm}"]
+        assert rel_err(ws(f"dpre.enc.{nm}", ref.shape), ref) < RTOL, nm
+    got = net.get_weights_dict(net.grads)
+    assert set(got) == set(vo.trainable_names(L, variant))
+    for k, v in got.items():
+        assert rel_err(v, g[k]) < RTOL, k
+
+
+@pytest.mark.parametrize("path,variant,L,B,seed", golden_cases())
+def test_golden_fixtures(path, variant, L, B, seed):
+    f = np.load(path, allow_pickle=False)
+    p = vo.init_params(L, variant, seed=seed, jitter=0.1)
+    eps = f["eps"] if variant == "vae" else None
+    net = _net(variant, L)
+    net.set_weights_dict(p)
+    recon, logits = net.decode(f["z"], want_logits=True)
+    assert rel_err(logits.cpu().numpy(), f["logits"]) < RTOL
+    assert rel_err(recon.cpu().numpy(), f["recon"]) < RTOL
+    zm, zlv, z = net.encode(f["x"], eps)
+    assert rel_err(z.cpu().numpy(), f["z"]) < RTOL
+    if variant == "vae":
+        assert rel_err(zm.cpu().numpy(), f["z_mean"]) < RTOL
+        assert rel_err(zlv.cpu().numpy(), f["z_log_var"]) < RTOL
+    # three Adam steps (lr 1e-3): losses and a few parameter slices
+    for t in (1, 2, 3):
+        losses = net.train_fwd_bwd(f["x"], eps).cpu().numpy()
+        if t == 1:
+            got = net.get_weights_dict(net.grads)
+            for k, v in got.items():
+                assert abs(v.astype(np.float64).sum() - float(f["gsum." + k])) <= 2e-5 * float(f["gabs." + k]) + 1e-12, k
+                scale = np.abs(v).max() + 1e-30
+                assert np.abs(v.ravel()[:16] - f["ghead." + k]).max() < 2e-5 * scale, k
+        assert abs(losses[0] - float(f[f"loss_step{t}"])) < 5e-5 * abs(float(f[f"loss_step{t}"])), t
+        net.adam_step(1e-3)
+        if t in (1, 3):
+            w = net.get_weights_dict()
+            for k in ("enc.conv2.kernel", "dec.deconv4.kernel", "dec.dense.gamma", "enc.conv1.bias"):
+                ref = f[f"p{t}.{k}"]
+                # Adam's first steps move every weight by ~lr regardless of the gradient scale: compare updates
+                assert np.abs(w[k].ravel()[:32] - ref).max() < 2e-2 * 1e-3 * t + 1e-6, (t, k)
+    sal = net.attribute(f["x"], [int(u) for u in f["units"]]).cpu().numpy()
+    # weights moved during the Adam steps: reload before comparing attribution
+    net.set_weights_dict(p)
+    sal = net.attribute(f["x"], [int(u) for u in f["units"]]).cpu().numpy()
+    assert rel_err(sal, f["saliency"]) < 5e-5
+    gxi = net.attribute(f["x"], [int(u) for u in f["units"]], grad_x_input=True).cpu().numpy()
+    assert rel_err(gxi, f["gxi"]) < 5e-5
+
+
+@pytest.mark.parametrize("variant", ["vae", "ae"])
+def test_attribution_matches_oracle(variant):
+    L, B = 28, 9
+    p, x, _ = _case(variant, L, B, seed=21)
+    net = _net(variant, L)
+    net.set_weights_dict(p)
+    units = [0, 3, 27]
+    got = net.attribute(x, units).cpu().numpy()
+    c = vo.encoder_fwd(p, np.asarray(x, dtype=np.float64), variant)
+    masks = device_masks(net, B, c, layers=["enc.conv1", "enc.conv2", "enc.conv3", "enc.dense"])
+    ref = vo.attribution(p, x, units, variant, masks=masks)[..., 0]
+    assert rel_err(got, ref) < RTOL
+    got2 = net.attribute(x, units, grad_x_input=True).cpu().numpy()
+    assert rel_err(got2, ref * np.asarray(x, dtype=np.float64)[None, ..., 0]) < RTOL
+
+
+def test_adam_kernel_is_the_tf_form():
+    """veex_adam against the float64 TF-form update on random buffers: epsilon sits outside the
+    bias correction, the step counter lives on the device, the gradient scale (1/world) is folded in."""
+    import torch
+    from vae_eeg_xai_amd._lib import lib, check, ptr, current_stream
+    rng = np.random.default_rng(0)
+    n = 4096 + 8
+    p0 = rng.standard_normal(n)
+    p = torch.tensor(p0, dtype=torch.float32, device="cuda")
+    m = torch.zeros(n, dtype=torch.float32, device="cuda")
+    v = torch.zeros(n, dtype=torch.float32, device="cuda")
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    alpha = torch.zeros(1, dtype=torch.float32, device="cuda")
+    pr, mr, vr = p.cpu().numpy().astype(np.float64), np.zeros(n), np.zeros(n)
+    lr, gscale = 1e-3, 0.5
+    for t in range(1, 5):
+        g64 = rng.standard_normal(n) * 10.0 ** rng.uniform(-9, 1, n)      # gradients across 10 decades
+        g = torch.tensor(g64, dtype=torch.float32, device="cuda")
+        check(lib.veex_adam(ptr(p), ptr(g), ptr(m), ptr(v), n, ptr(step), ptr(alpha), lr, gscale, 0.9, 0.999, 1e-7,
+                            current_stream()))
+        gs = g.cpu().numpy().astype(np.float64) * gscale
+        mr = 0.9 * mr + 0.1 * gs
+        vr = 0.999 * vr + 0.001 * gs * gs
+        a = lr * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        pr = pr - a * mr / (np.sqrt(vr) + 1e-7)
+        assert int(step.item()) == t
+        assert abs(alpha.item() - a) < 1e-6 * a
+        upd_err = np.abs(p.cpu().numpy() - pr).max()
+        assert upd_err < 2e-6 * lr + 1.5e-7 * np.abs(pr).max(), (t, upd_err)
+        assert rel_err(m.cpu().numpy(), mr) < 1e-6
+        assert rel_err(v.cpu().numpy(), vr) < 1e-6
+
+
+def test_three_training_steps_track_the_oracle():
+    L, B = 8, 4
+    p, x, eps = _case("vae", L, B, seed=5)
+    net = _net("vae", L)
+    net.set_weights_dict(p)
+    names = vo.trainable_names(L, "vae")
+    m = {k: np.zeros_like(p[k]) for k in names}
+    v = {k: np.zeros_like(p[k]) for k in names}
+    pp = {k: a.copy() for k, a in p.items()}
+    lr = 1e-5                                     # the reference's learning rate (train.py:106)
+    for t in range(1, 4):
+        ref_loss = vo.train_step(pp, m, v, t, lr, x, eps)[0]
+        loss = float(net.train_fwd_bwd(x, eps).cpu()[0])
+        net.adam_step(lr)
+        assert abs(loss - ref_loss) < RTOL * abs(ref_loss)
+    w = net.get_weights_dict()
+    mm = net.get_weights_dict(net.adam_m)
+    for k in names:
+        # Adam's first steps move each weight by ~lr*sign(g); weights whose gradient is at fp32 noise level
+        # are ill-conditioned, so bound the update error by a fraction of the step, not by 1e-5
+        upd_err = float(np.abs((w[k].astype(np.float64) - p[k]) - (pp[k] - p[k])).max())
+        assert upd_err < 0.2 * 3 * lr + 1e-7 * float(np.abs(p[k]).max()), (k, upd_err)
+        assert rel_err(mm[k], m[k]) < 1e-4, k
+
+
+def test_philox_epsilon_matches_restatement_and_is_split_invariant():
+    import torch
+    L, B = 28, 16
+    p, x, _ = _case("vae", L, B, seed=8)
+    net = _net("vae", L)
+    net.set_weights_dict(p)
+    net.philox_seed = 1234
+    net.train_fwd_bwd(x, None, first_sample=100)
+    eps_dev = net.ws_region(B, "eps").cpu().numpy().reshape(B, L)
+    ref = vo.philox_normal(1234, 100, B, L)
+    assert np.abs(eps_dev - ref).max() < 2e-5     # fp32 log/sin/cos vs float64
+    # a rank that owns samples 104..111 of the same global batch draws the same noise
+    net.train_fwd_bwd(x[4:12], None, first_sample=104)
+    part = net.ws_region(8, "eps").cpu().numpy().reshape(8, L)
+    assert np.array_equal(part, eps_dev[4:12])
+    torch.cuda.synchronize()
+
+
+def test_full_size_properties_batch512():
+    """configs[1] size (batch 512, L=28): size-independent properties instead of a 512-sample oracle run:
+    bitwise run-to-run reproducibility (no float atomics), gradient of the batch = mean of the gradients
+    of its halves (tiling independence), finite outputs, loss decrease under Adam."""
+    import torch
+    L, B = 28, 512
+    net = _net("vae", L)
+    net.init_weights(seed=0)
+    x = vo.synth_topomaps(B, 77)
+    eps = np.random.default_rng(1).standard_normal((B, L)).astype(np.float32)
+    l1 = net.train_fwd_bwd(x, eps).clone()
+    g1 = net.grads.clone()
+    l2 = net.train_fwd_bwd(x, eps).clone()
+    assert torch.equal(g1, net.grads) and torch.equal(l1, l2)
+    assert torch.isfinite(g1).all()
+    n = net.n_params
+
+    def compare(tag, got_flat, l2_tol, max_tol):
+        for name, ref in net.named_views(g1):
+            got = net.view([s for s in net.specs if s.name == name][0], got_flat)
+            l2 = ((got - ref).norm() / (ref.norm() + 1e-30)).item()
+            mx = (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-30)
+            assert l2 < l2_tol and mx < max_tol, (tag, name, l2, mx)
+
+    # (1) permuting the batch leaves every sample's forward bit-identical (same tiles, same K order), so the
+    #     gradients may only differ by the order of the fp32 sums over the batch
+    perm = np.random.default_rng(3).permutation(B)
+    lp = net.train_fwd_bwd(x[perm], eps[perm]).clone()
+    compare("perm", net.grads.clone(), 5e-6, 2e-5)
+    assert abs(lp[0].item() - l1[0].item()) < 1e-6 * abs(l1[0].item())
+    # (2) gradient of the batch = mean of the gradients of its halves.  A different batch size changes the
+    #     split-K plan of the dense layers, hence the last bits of the latent code, hence a few ReLU decisions
+    #     at pre-activations ~1e-7 (measured: ~10 of 1.2e8), each of which moves that sample's gradient by
+    #     O(1e-3): only a loose bound holds.
+    net.train_fwd_bwd(x[:256], eps[:256])
+    ga = net.grads.clone()
+    net.train_fwd_bwd(x[256:], eps[256:])
+    gb = net.grads.clone()
+    compare("halves", 0.5 * (ga + gb), 2e-3, 5e-2)
+    assert abs(0.5 * (ga[n] + gb[n]).item() - l1[0].item()) < 1e-5 * abs(l1[0].item())
+    first = l1[0].item()
+    for _ in range(10):
+        net.train_fwd_bwd(x, eps)
+        net.adam_step(1e-3)
+    last = net.train_fwd_bwd(x, eps)[0].item()
+    assert last < first

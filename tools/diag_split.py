@@ -1,0 +1,22 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from oracle import vae_oracle as vo
+from vae_eeg_xai_amd.net import Net
+L, B = 28, 512
+net = Net(L, "vae"); net.init_weights(seed=0)
+x = vo.synth_topomaps(B, 77)
+eps = np.random.default_rng(1).standard_normal((B, L)).astype(np.float32)
+names = ["act.enc.conv1","act.enc.conv2","act.enc.conv3","act.enc.dense","mulv","z","act.dec.dense","act.dec.deconv1","act.dec.deconv5","dlogit",
+         "dpre.dec.deconv5","dpre.dec.deconv1","g.dec.dense","dpre.dec.dense","dz","dmulv","dpre.enc.dense","dpre.enc.conv3","dpre.enc.conv1"]
+net.train_fwd_bwd(x, eps); torch.cuda.synchronize()
+full = {n: net.ws_region(B, n).clone() for n in names}
+gfull = net.grads.clone()
+net.train_fwd_bwd(x[:256], eps[:256]); torch.cuda.synchronize()
+half = {n: net.ws_region(256, n).clone() for n in names}
+for n in names:
+    f = full[n][:half[n].numel()]
+    h = half[n]
+    scale = 2.0 if n.startswith(("d", "g.")) else 1.0   # gradients carry 1/B
+    d = (f * scale - h)
+    print(f"{n:20s} max|d|={d.abs().max().item():.3e} rel={d.abs().max().item()/(h.abs().max().item()+1e-30):.3e} nnz={(d!=0).sum().item()} / {d.numel()}")

@@ -49,7 +49,7 @@ class WgradDesc(C.Structure):
     ]
 
 
-_P, _I, _L, _F, _U = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_ulonglong
+_P, _I, _L, _F, _U, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_ulonglong, C.c_double
 
 # name -> (restype, argtypes); every symbol include/veex.h declares
 SIGNATURES = {
@@ -71,7 +71,7 @@ SIGNATURES = {
     "veex_bnrelu_bwd_rows": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "veex_colsum_finalize": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "veex_slab_sum": (_I, [_P, _I, _L, _L, _P, _P, _I, _I, _P]),
-    "veex_adam": (_I, [_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _F, _P]),
+    "veex_adam": (_I, [_P, _P, _P, _P, _L, _P, _P, _D, _D, _D, _D, _D, _P]),
     "veex_net_create": (_P, [_I, _I]),
     "veex_net_destroy": (None, [_P]),
     "veex_net_param_floats": (_L, [_P]),

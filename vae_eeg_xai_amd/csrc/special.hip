@@ -459,11 +459,11 @@ __global__ __launch_bounds__(1024) void slab_sum_tall_kernel(const float* __rest
 // keras.optimizers.legacy.Adam: epsilon outside the bias correction.
 // state[0] = step count t (as float bits of an int), alpha written to state_alpha.
 // ---------------------------------------------------------------------------------------
-__global__ void adam_prepare_kernel(int* __restrict__ step, float* __restrict__ alpha, float lr, float b1, float b2) {
+__global__ void adam_prepare_kernel(int* __restrict__ step, float* __restrict__ alpha, double lr, double b1, double b2) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const int t = step[0] + 1;
     step[0] = t;
-    const double a = (double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t));
+    const double a = lr * sqrt(1.0 - pow(b2, (double)t)) / (1.0 - pow(b1, (double)t));
     alpha[0] = (float)a;
   }
 }
@@ -471,7 +471,7 @@ __global__ void adam_prepare_kernel(int* __restrict__ step, float* __restrict__ 
 __global__ __launch_bounds__(256) void adam_apply_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                          float* __restrict__ m, float* __restrict__ v, long long n4,
                                                          const float* __restrict__ alpha_p, float gscale, float b1,
-                                                         float b2, float eps) {
+                                                         float omb1, float b2, float omb2, float eps) {
   const float alpha = alpha_p[0];
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
@@ -479,10 +479,10 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(float* __restrict__ p, 
     float4 mm = reinterpret_cast<float4*>(m)[i];
     float4 vv = reinterpret_cast<float4*>(v)[i];
     gg.x *= gscale; gg.y *= gscale; gg.z *= gscale; gg.w *= gscale;
-    mm.x = b1 * mm.x + (1.f - b1) * gg.x; mm.y = b1 * mm.y + (1.f - b1) * gg.y;
-    mm.z = b1 * mm.z + (1.f - b1) * gg.z; mm.w = b1 * mm.w + (1.f - b1) * gg.w;
-    vv.x = b2 * vv.x + (1.f - b2) * gg.x * gg.x; vv.y = b2 * vv.y + (1.f - b2) * gg.y * gg.y;
-    vv.z = b2 * vv.z + (1.f - b2) * gg.z * gg.z; vv.w = b2 * vv.w + (1.f - b2) * gg.w * gg.w;
+    mm.x = b1 * mm.x + omb1 * gg.x; mm.y = b1 * mm.y + omb1 * gg.y;
+    mm.z = b1 * mm.z + omb1 * gg.z; mm.w = b1 * mm.w + omb1 * gg.w;
+    vv.x = b2 * vv.x + omb2 * gg.x * gg.x; vv.y = b2 * vv.y + omb2 * gg.y * gg.y;
+    vv.z = b2 * vv.z + omb2 * gg.z * gg.z; vv.w = b2 * vv.w + omb2 * gg.w * gg.w;
     pp.x -= alpha * mm.x / (sqrtf(vv.x) + eps); pp.y -= alpha * mm.y / (sqrtf(vv.y) + eps);
     pp.z -= alpha * mm.z / (sqrtf(vv.z) + eps); pp.w -= alpha * mm.w / (sqrtf(vv.w) + eps);
     reinterpret_cast<float4*>(p)[i] = pp;
@@ -651,12 +651,16 @@ int veex_slab_sum(const float* slab, int nsplit, long long stride, long long n, 
   return 0;
 }
 
-int veex_adam(float* p, const float* g, float* m, float* v, long long n, int* step, float* alpha, float lr,
-               float gscale, float b1, float b2, float eps, hipStream_t st) {
+int veex_adam(float* p, const float* g, float* m, float* v, long long n, int* step, float* alpha, double lr,
+              double gscale, double b1, double b2, double eps, hipStream_t st) {
   if (n % 4 != 0) { veex_set_error("adam: element count must be a multiple of 4"); return -1; }
+  if (p == nullptr || g == nullptr || m == nullptr || v == nullptr || step == nullptr || alpha == nullptr) {
+    veex_set_error("adam: null argument"); return -1;
+  }
   hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, st, step, alpha, lr, b1, b2);
+  // (1-beta) is formed in double and rounded once (1.f - 0.999f is off by 1.3e-5 relative)
   hipLaunchKernelGGL(adam_apply_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, st, p, g, m, v, n / 4, alpha,
-                     gscale, b1, b2, eps);
+                     (float)gscale, (float)b1, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps);
   VEEX_CHECK_LAUNCH();
   return 0;
 }

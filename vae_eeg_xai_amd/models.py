@@ -1,0 +1,364 @@
+"""Drop-in counterpart of the reference's ``models.py`` (sample, Encoder, Decoder, VAE) on the
+MI355X HIP library.  Same class names, constructor arguments, call signatures and return
+structure (reference models.py:10-22,122-312); everything numerical runs in libveex.so.
+
+Differences a caller can observe (documented, not silent):
+  * returned tensors are ``DeviceArray`` objects (ndarray protocol; data stays in HBM until used);
+  * ``sample`` / ``Encoder.__call__`` accept an optional injected ``epsilon``; without it epsilon
+    comes from the device Philox generator (the reference's tf.random.normal is unseeded);
+  * initial weights are drawn from NumPy's generator (same distributions as he_uniform /
+    glorot_uniform, different stream than TensorFlow's);
+  * ``save_weights`` writes ``<path>.npz`` (a TF object-graph checkpoint cannot be produced).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .net import Net, _as_device_f32
+from .keras_compat import Adam, EarlyStopping, History, tf  # noqa: F401  (re-exported like the reference)
+from . import dist as vdist
+
+keras = tf.keras
+
+
+class DeviceArray:
+    """ndarray-protocol view of a device tensor: np.asarray / indexing / .shape / .reshape /
+    np.quantile / np.copy work as on the tensors the reference returns (analysis.py:38-52,243,492)."""
+
+    __array_priority__ = 100
+
+    def __init__(self, t: torch.Tensor):
+        self._t = t
+
+    # ndarray protocol
+    def __array__(self, dtype=None, copy=None):
+        a = self._t.detach().cpu().numpy()
+        return a.astype(dtype) if dtype is not None else a
+
+    def numpy(self):
+        return self.__array__()
+
+    @property
+    def shape(self):
+        return tuple(self._t.shape)
+
+    @property
+    def dtype(self):
+        return np.dtype("float32")
+
+    @property
+    def ndim(self):
+        return self._t.dim()
+
+    def __len__(self):
+        return self._t.shape[0]
+
+    def __getitem__(self, idx):
+        return self.__array__()[idx]
+
+    def __iter__(self):
+        return iter(self.__array__())
+
+    def reshape(self, *shape):
+        return self.__array__().reshape(*shape)
+
+    def copy(self):
+        return self.__array__().copy()
+
+    def __repr__(self):
+        return f"DeviceArray(shape={self.shape}, device={self._t.device})"
+
+
+def _host_rng_eps(shape, generator):
+    if generator is None:
+        return None
+    if isinstance(generator, np.random.Generator):
+        return generator.standard_normal(shape).astype(np.float32)
+    raise TypeError("generator must be a numpy.random.Generator")
+
+
+def sample(z_mean, z_log_var, epsilon=None, generator=None):
+    """Reparameterisation trick (reference models.py:10-22): z = mean + exp(0.5*log_var) * eps.
+    Runs the fused HIP reparameterisation kernel; ``epsilon`` (B,L) injects the noise."""
+    from . import _lib
+    from ._lib import lib, check, ptr
+    zm = _as_device_f32(z_mean, torch.device("cuda", torch.cuda.current_device()))
+    zlv = _as_device_f32(z_log_var, zm.device)
+    B, L = zm.shape
+    if epsilon is None:
+        epsilon = _host_rng_eps((B, L), generator)
+    mulv = torch.cat([zm, zlv], dim=1).contiguous()
+    z = torch.empty_like(zm)
+    if epsilon is None:
+        eps = torch.empty_like(zm)
+        seed = int(np.random.SeedSequence().entropy % (1 << 63))
+        check(lib.veex_reparam_kl_fwd(ptr(mulv), ptr(eps), ptr(z), None, B, L, 1, seed, 0, _lib.current_stream()))
+    else:
+        eps = _as_device_f32(epsilon, zm.device)
+        check(lib.veex_reparam_kl_fwd(ptr(mulv), ptr(eps), ptr(z), None, B, L, 0, 0, 0, _lib.current_stream()))
+    return DeviceArray(z)
+
+
+class _LayerHandle:
+    """Named handle on one layer's tensors (the reference exposes conv1.., dense, z_mean, ... attributes)."""
+
+    def __init__(self, owner, prefix):
+        self._owner, self._prefix = owner, prefix
+
+    def get_weights(self):
+        net = self._owner._net
+        return [net.view(s).detach().cpu().numpy().copy() for s in net.specs if s.name.startswith(self._prefix + ".")]
+
+
+class Encoder:
+    """Encoder(latent_dimension) -> (z_mean, z_log_var, z)  (reference models.py:211-253)."""
+
+    _variant = "vae"
+
+    def __init__(self, latent_dimension):
+        self.latent_dim = int(latent_dimension)
+        self._net = Net(self.latent_dim, self._variant)
+        self._net.init_weights(seed=42)
+        for nm in ("conv1", "conv2", "conv3", "dense"):
+            setattr(self, nm, _LayerHandle(self, f"enc.{nm}"))
+        self.flatten = None
+        if self._variant == "vae":
+            self.z_mean = _LayerHandle(self, "enc.z_mean")
+            self.z_log_var = _LayerHandle(self, "enc.z_log_var")
+            self.sampling = sample
+
+    def __call__(self, inputs, training=None, mask=None, epsilon=None):
+        # ``training`` is accepted and ignored exactly like the reference: BatchNorm always runs in
+        # inference mode there (models.py:244-253 never forwards it)
+        zm, zlv, z = self._net.encode(inputs, epsilon)
+        return DeviceArray(zm), DeviceArray(zlv), DeviceArray(z)
+
+    call = __call__
+
+
+class Decoder:
+    """Decoder() : z -> (B,40,40,1) reconstruction  (reference models.py:256-312)."""
+
+    _variant = "vae"
+
+    def __init__(self):
+        self._net: Optional[Net] = None
+        for nm in ("dense", "deconv1", "deconv2", "deconv3", "deconv4", "deconv5", "deconv6"):
+            setattr(self, nm, _LayerHandle(self, f"dec.{nm}"))
+
+    def _bind(self, net: Net):
+        self._net = net
+
+    def __call__(self, inputs, training=None, mask=None):
+        z = inputs._t if isinstance(inputs, DeviceArray) else inputs
+        if self._net is None:      # stand-alone decoder: latent size from the input
+            L = int(np.asarray(z.shape)[1])
+            self._net = Net(L, self._variant)
+            self._net.init_weights(seed=42)
+        return DeviceArray(self._net.decode(z))
+
+    call = __call__
+
+
+class _Mean:
+    """keras.metrics.Mean look-alike backed by the device-side accumulators."""
+
+    def __init__(self, name, owner, idx):
+        self.name, self._owner, self._idx = name, owner, idx
+
+    def result(self):
+        m = self._owner._net.metrics
+        return float((m[self._idx] / torch.clamp(m[3], min=1.0)).item())
+
+    def reset_state(self):
+        self._owner._net.metrics.zero_()
+
+
+class VAE:
+    """VAE(encoder, decoder, epochs, l_rate, batch_size, patience)  (reference models.py:122-207)."""
+
+    _metric_names = ("loss", "reconstruction_loss", "kl_loss")
+    _variant = "vae"
+
+    def __init__(self, encoder, decoder, epochs=None, l_rate=None, batch_size=None, patience=None, **kwargs):
+        self.encoder = encoder
+        self.decoder = decoder
+        self.epochs = epochs  # For grid search (kept like the reference; never read)
+        self.l_rate = l_rate
+        self.batch_size = batch_size
+        self.patience = patience
+        self._net: Net = encoder._net
+        if decoder._net is not None and decoder._net is not self._net:
+            # adopt the decoder's existing weights
+            src = decoder._net.get_weights_dict()
+            self._net.set_weights_dict({k: v for k, v in src.items() if k.startswith("dec.")})
+        decoder._bind(self._net)
+        self.optimizer = None
+        self.stop_training = False
+        self.total_loss_tracker = _Mean("total_loss", self, 0)
+        self.reconstruction_loss_tracker = _Mean("reconstruction_loss", self, 1)
+        self.kl_loss_tracker = _Mean("kl_loss", self, 2)
+
+    # ---- keras.Model surface used by the reference ----
+    @property
+    def metrics(self):
+        return [self.total_loss_tracker, self.reconstruction_loss_tracker, self.kl_loss_tracker]
+
+    @property
+    def trainable_weights(self):
+        return [v for _, v in self._net.named_views(trainable_only=True)]
+
+    def compile(self, optimizer=None, **kwargs):
+        self.optimizer = optimizer if optimizer is not None else Adam()
+
+    def _lr(self):
+        if self.optimizer is None:
+            raise RuntimeError("call compile(optimizer) before training")
+        return float(self.optimizer.learning_rate)
+
+    def _logs(self, prefix=""):
+        m = self._net.metrics.detach().cpu().numpy()
+        cnt = max(float(m[3]), 1.0)
+        vals = (m[0] / cnt, m[1] / cnt, m[2] / cnt)
+        return {prefix + k: float(v) for k, v in zip(self._metric_names, vals)}
+
+    def call(self, inputs, training=None, mask=None, epsilon=None):
+        """decoder(encoder(x)[2]) -- decodes the *sampled* z like the reference (models.py:135-138)."""
+        recon, _ = self._net.forward(inputs, epsilon, want_recon=True)
+        return DeviceArray(recon)
+
+    __call__ = call
+
+    def train_step(self, data, epsilon=None):
+        """One optimisation step (reference models.py:148-180); returns the running means."""
+        x, _labels = data
+        self._step(x, epsilon)
+        return self._logs()
+
+    def test_step(self, data, epsilon=None):
+        x, _labels = data
+        self._net.forward(x, epsilon, want_recon=False, accumulate_metrics=True)
+        return self._logs()
+
+    def _step(self, x, epsilon=None, first_sample=None):
+        net = self._net
+        world = vdist.world_size()
+        net.train_fwd_bwd(x, epsilon, accumulate_metrics=(world == 1), first_sample=first_sample)
+        if world > 1:
+            vdist.allreduce_sum_(net.grads)        # gradients and the 3 loss scalars in one collective
+            net.metrics[:3] += net.grads[net.n_params:net.n_params + 3] / world
+            net.metrics[3] += 1.0
+        net.adam_step(self._lr(), 1.0 / world)
+
+    def train_on_batch(self, x, y=None):
+        self._net.metrics.zero_()
+        self._step(x)
+        logs = self._logs()
+        return [logs[k] for k in self._metric_names]
+
+    def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None, validation_data=None,
+            shuffle=True, seed=None, **kwargs):
+        """keras Model.fit as the reference calls it (train.py:141-142,196-197): positional
+        (x, y, batch_size, epochs); y is ignored (train_step unpacks and drops it); shuffles every
+        epoch, keeps the last partial batch, logs the unweighted running mean over batches.
+        Under torch.distributed every rank takes its slice of each global batch."""
+        net = self._net
+        batch_size = int(batch_size or 32)
+        world, rank = vdist.world_size(), vdist.rank()
+        xd = _as_device_f32(x, net.device)
+        N = xd.shape[0]
+        xv = None
+        if validation_data is not None:
+            xv = _as_device_f32(validation_data[0], net.device)
+        callbacks = list(callbacks or [])
+        for cb in callbacks:
+            if hasattr(cb, "on_train_begin"):
+                cb.on_train_begin()
+        hist = History()
+        rng = np.random.default_rng(seed)
+        self.stop_training = False
+        for epoch in range(int(epochs)):
+            perm = rng.permutation(N) if shuffle else np.arange(N)
+            perm_d = torch.from_numpy(perm).to(net.device)
+            net.metrics.zero_()
+            for s in range(0, N, batch_size):
+                idx = perm_d[s:s + batch_size]
+                if world > 1:
+                    lo, hi = vdist.shard_range(idx.shape[0], rank, world)
+                    idx = idx[lo:hi]
+                    if idx.numel() == 0:
+                        raise ValueError("global batch smaller than the world size")
+                xb = xd.index_select(0, idx)
+                self._step(xb)
+            logs = self._logs()
+            if xv is not None:
+                net.metrics.zero_()
+                for s in range(0, xv.shape[0], batch_size):
+                    net.forward(xv[s:s + batch_size], None, want_recon=False, accumulate_metrics=True)
+                logs.update(self._logs("val_"))
+            hist.append(epoch, logs)
+            if verbose:
+                print(f"Epoch {epoch + 1}/{epochs} - " + " - ".join(f"{k}: {v:.4f}" for k, v in logs.items()))
+            for cb in callbacks:
+                if hasattr(cb, "on_epoch_end"):
+                    cb.on_epoch_end(epoch, logs)
+                if getattr(cb, "stop_training", False):
+                    self.stop_training = True
+            if self.stop_training:
+                break
+        self.history = hist
+        return hist
+
+    def predict(self, x, batch_size=32, verbose=0, epsilon=None, **kwargs):
+        """keras Model.predict: batches of 32 by default, stochastic (sampled z) like VAE.call."""
+        net = self._net
+        xd = _as_device_f32(x, net.device)
+        outs = []
+        for s in range(0, xd.shape[0], int(batch_size)):
+            e = None if epsilon is None else epsilon[s:s + int(batch_size)]
+            recon, _ = net.forward(xd[s:s + int(batch_size)], e, want_recon=True)
+            outs.append(recon)
+        return torch.cat(outs, dim=0).cpu().numpy()
+
+    def evaluate(self, x, y=None, batch_size=32, verbose=0, **kwargs):
+        net = self._net
+        xd = _as_device_f32(x, net.device)
+        net.metrics.zero_()
+        for s in range(0, xd.shape[0], int(batch_size)):
+            net.forward(xd[s:s + int(batch_size)], None, want_recon=False, accumulate_metrics=True)
+        logs = self._logs()
+        return [logs[k] for k in self._metric_names]
+
+    # ---- weights ----
+    def get_weights(self):
+        return self._net.get_weights()
+
+    def set_weights(self, weights):
+        self._net.set_weights(weights)
+
+    def save_weights(self, filepath, save_format=None, **kwargs):
+        d = self._net.get_weights_dict()
+        np.savez(str(filepath) + ".npz", **d)
+
+    def load_weights(self, filepath, **kwargs):
+        path = str(filepath)
+        if not path.endswith(".npz"):
+            path += ".npz"
+        with np.load(path, allow_pickle=False) as f:
+            self._net.set_weights_dict({k: f[k] for k in f.files})
+
+    # ---- gradient attribution (north_star item 3; not in the reference) ----
+    def attribute(self, x, units, grad_x_input=False, batch_size=4096):
+        """Saliency / gradient*input maps of latent units wrt the input: (len(units), N, 40, 40)."""
+        net = self._net
+        xd = _as_device_f32(x, net.device)
+        outs = []
+        for s in range(0, xd.shape[0], int(batch_size)):
+            outs.append(net.attribute(xd[s:s + int(batch_size)], units, grad_x_input))
+        return torch.cat(outs, dim=1).cpu().numpy()
+
+
+__all__ = ["sample", "Encoder", "Decoder", "VAE", "Adam", "EarlyStopping", "History", "DeviceArray", "tf", "keras"]
