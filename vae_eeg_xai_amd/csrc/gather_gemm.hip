@@ -18,6 +18,7 @@
 // gradient this GEMM produces (writes d(pre-activation) and per-tile column sums for dgamma,
 // dbeta, dbias);  RAW = split-K partial slab.
 #include "veex_internal.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -356,17 +357,21 @@ __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off)
   return make_float4(f[0], f[1], f[2], f[3]);
 }
 
-template <int BM, int BN, int WM, int WN, bool MODE1, int AFF>
+template <int BM, int BN, int WM, int WN, bool MODE1, int AFF, int BK, int DBG = 0>
 __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 32, NT = WTN / 32;
-  constexpr int APASS = BM / 64;
-  constexpr int A_ELEMS = BM * VEEX_LDK;
+  constexpr int LDK = BK + 4;          // padded k-stride of the [row][k] LDS tiles
+  constexpr int QK = BK / 4;           // 16-byte quads per tile row
+  constexpr int RP = 256 / QK;         // tile rows staged per pass
+  constexpr int APASS = BM / RP;
+  constexpr int A_ELEMS = BM * LDK;
   constexpr int LDN = BN + 4;
-  constexpr int B_ELEMS = MODE1 ? BN * VEEX_LDK : VEEX_BK * LDN;
-  constexpr int BPASS = MODE1 ? BN / 64 : (VEEX_BK * BN / 4) / 256;
+  constexpr int B_ELEMS = MODE1 ? BN * LDK : BK * LDN;
+  constexpr int BPASS = MODE1 ? BN / RP : (BK * BN / 4) / 256;
   constexpr int QN = BN / 4;
   constexpr int RPP = 256 / QN;
+  static_assert(APASS >= 1 && BPASS >= 1, "tile too small for this BK");
   static_assert(WM * WN == 4, "4 waves");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
     nky = (p.kh - py + 1) >> 1;
     nkx = (p.kw - px + 1) >> 1;
   }
-  const int cpt = (p.Cin + VEEX_BK - 1) / VEEX_BK;
+  const int cpt = (p.Cin + BK - 1) / BK;
   const int nchunks = nky * nkx * cpt;
   const int c_begin = blockIdx.z * p.chunks_per_split;
   const int c_end = min(nchunks, c_begin + p.chunks_per_split);
@@ -423,14 +428,14 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
   const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(AFF != 0 ? p.a_shift : p.A), 0, (int)aff_bytes, 0x00020000);
 
-  // ---- per-row state of the A loader: rows (tid>>2)+64*i, k-quad (tid&3) ----
-  const int q = tid & 3, lr = tid >> 2;
+  // ---- per-row state of the A loader: rows (tid/QK)+RP*i, k-quad (tid%QK) ----
+  const int q = tid % QK, lr = tid / QK;
   int a_rowbase[APASS];        // byte offset of (row pixel at phase tap (0,0), channel 4q); may be "virtual"
   int a_nbase[APASS];          // byte offset of the sample (for AFF==2)
   unsigned a_mask[APASS];      // bit t set <=> tap index t of this phase reads an in-bounds pixel
 #pragma unroll
   for (int i = 0; i < APASS; ++i) {
-    const int m = m0 + lr + 64 * i;
+    const int m = m0 + lr + RP * i;
     a_rowbase[i] = 0; a_mask[i] = 0u; a_nbase[i] = 0;
     if (m < Mph) {
       const int n = m / HWp, rem = m - n * HWp;
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
 #pragma unroll
   for (int i = 0; i < BPASS; ++i) {
     if (MODE1) {   // [tap][Cout][Cin]: row n, quad q along Cin
-      const int n = n0 + lr + 64 * i;
+      const int n = n0 + lr + RP * i;
       b_ok[i] = n < p.Cout;
       b_rowbase[i] = (n * p.Cin + 4 * q) * 4;
     } else {       // [tap][Cin][Cout]: row k, quad nq along Cout
@@ -470,15 +475,17 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
   }
   const int tap_bytes = p.Cin * p.Cout * 4;
 
-  float4 ra[APASS], rb[BPASS], rsc[AFF == 2 ? APASS : 1], rsh[AFF == 2 ? APASS : 1];
-  bool rok[APASS];
+  struct Stage {   // one K-chunk in flight from global memory (registers)
+    float4 ra[APASS], rb[BPASS], rsc[AFF == 2 ? APASS : 1], rsh[AFF == 2 ? APASS : 1];
+    bool rok[APASS];
+  };
 
-  auto load_chunk = [&](int c, bool cvalid) {
+  auto load_chunk = [&](Stage& st, int c, bool cvalid) {
     const int tapi = c / cpt;
     const int cc = c - tapi * cpt;
     const int ia = tapi / nkx, ib = tapi - ia * nkx;
     const int tap = (kys + kstep * ia) * p.kw + (kxs + kstep * ib);
-    const int ci0 = cc * VEEX_BK;
+    const int ci0 = cc * BK;
     const int dpix = ia * p.Win + ib;
     const int delta = (MODE1 ? -dpix : dpix) * p.Cin * 4 + ci0 * 4;
     const bool kq = cvalid && (ci0 + 4 * q < p.Cin);
@@ -486,18 +493,18 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
     for (int i = 0; i < APASS; ++i) {
       const bool ok = kq && ((a_mask[i] >> tapi) & 1u);
       const unsigned off = ok ? (unsigned)(a_rowbase[i] + delta) : VEEX_OOB;
-      ra[i] = bload4(rA, off);
-      rok[i] = ok;
+      st.ra[i] = bload4(rA, off);
+      st.rok[i] = ok;
       if (AFF == 2) {
         const unsigned ao = ok ? (unsigned)(a_rowbase[i] + delta - a_nbase[i]) : VEEX_OOB;
-        rsc[i] = bload4(rS, ao);
-        rsh[i] = bload4(rH, ao);
+        st.rsc[i] = bload4(rS, ao);
+        st.rsh[i] = bload4(rH, ao);
       }
     }
     if (AFF == 1) {
       const unsigned ao = kq ? (unsigned)(((ci0 + 4 * q) & p.aff_mask) * 4) : VEEX_OOB;
-      rsc[0] = bload4(rS, ao);
-      rsh[0] = bload4(rH, ao);
+      st.rsc[0] = bload4(rS, ao);
+      st.rsh[0] = bload4(rH, ao);
     }
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
@@ -510,28 +517,28 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
         ok = cvalid && b_ok[i] && (ci0 + kr + RPP * i < p.Cin);
         off = (unsigned)(tap * tap_bytes + ci0 * p.Cout * 4 + b_rowbase[i]);
       }
-      rb[i] = bload4(rW, ok ? off : VEEX_OOB);
+      st.rb[i] = bload4(rW, ok ? off : VEEX_OOB);
     }
   };
 
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](const Stage& st, int buf) {
     float* as = As + buf * A_ELEMS;
     float* bs = Bs + buf * B_ELEMS;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
-      float4 v = ra[i];
+      float4 v = st.ra[i];
       if (AFF != 0) {
-        const float4 sc = rsc[AFF == 2 ? i : 0], sh = rsh[AFF == 2 ? i : 0];
+        const float4 sc = st.rsc[AFF == 2 ? i : 0], sh = st.rsh[AFF == 2 ? i : 0];
         // padding pixels must stay 0 (the shift only applies to real pixels)
-        v.x = rok[i] ? fmaf(v.x, sc.x, sh.x) : 0.f; v.y = rok[i] ? fmaf(v.y, sc.y, sh.y) : 0.f;
-        v.z = rok[i] ? fmaf(v.z, sc.z, sh.z) : 0.f; v.w = rok[i] ? fmaf(v.w, sc.w, sh.w) : 0.f;
+        v.x = st.rok[i] ? fmaf(v.x, sc.x, sh.x) : 0.f; v.y = st.rok[i] ? fmaf(v.y, sc.y, sh.y) : 0.f;
+        v.z = st.rok[i] ? fmaf(v.z, sc.z, sh.z) : 0.f; v.w = st.rok[i] ? fmaf(v.w, sc.w, sh.w) : 0.f;
       }
-      *reinterpret_cast<float4*>(as + (lr + 64 * i) * VEEX_LDK + 4 * q) = v;
+      *reinterpret_cast<float4*>(as + (lr + RP * i) * LDK + 4 * q) = v;
     }
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
-      if (MODE1) *reinterpret_cast<float4*>(bs + (lr + 64 * i) * VEEX_LDK + 4 * q) = rb[i];
-      else       *reinterpret_cast<float4*>(bs + (kr + RPP * i) * LDN + 4 * nq) = rb[i];
+      if (MODE1) *reinterpret_cast<float4*>(bs + (lr + RP * i) * LDK + 4 * q) = st.rb[i];
+      else       *reinterpret_cast<float4*>(bs + (kr + RPP * i) * LDN + 4 * nq) = st.rb[i];
     }
   };
 
@@ -543,28 +550,24 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load_chunk(c_begin, c_begin < c_end);
-  store_chunk(0);
-  __syncthreads();
-
-  for (int c = c_begin; c < c_end; ++c) {
-    const int cur = (c - c_begin) & 1;
-    load_chunk(c + 1, c + 1 < c_end);   // past the end: every offset out of range -> zeros, never read
-    const float* as = As + cur * A_ELEMS + (wm * WTM + l31) * VEEX_LDK + 8 * lh;
-    const float* bs = MODE1 ? (Bs + cur * B_ELEMS + (wn * WTN + l31) * VEEX_LDK + 8 * lh)
-                            : (Bs + cur * B_ELEMS + (8 * lh) * LDN + wn * WTN + l31);
+  // K order inside a chunk is permuted: lanes 0-31 feed k = 0..BK/2-1, lanes 32-63 the upper half
+  // (A and B use the same permutation, so the sum is unchanged).
+  auto compute = [&](int cur) {
+    const float* as = As + cur * A_ELEMS + (wm * WTM + l31) * LDK + (BK / 2) * lh;
+    const float* bs = MODE1 ? (Bs + cur * B_ELEMS + (wn * WTN + l31) * LDK + (BK / 2) * lh)
+                            : (Bs + cur * B_ELEMS + ((BK / 2) * lh) * LDN + wn * WTN + l31);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < BK / 8; ++half) {
       float av[MT][4], bv[NT][4];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        const float4 t = *reinterpret_cast<const float4*>(as + i * 32 * VEEX_LDK + 4 * half);
+        const float4 t = *reinterpret_cast<const float4*>(as + i * 32 * LDK + 4 * half);
         av[i][0] = t.x; av[i][1] = t.y; av[i][2] = t.z; av[i][3] = t.w;
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         if (MODE1) {
-          const float4 t = *reinterpret_cast<const float4*>(bs + j * 32 * VEEX_LDK + 4 * half);
+          const float4 t = *reinterpret_cast<const float4*>(bs + j * 32 * LDK + 4 * half);
           bv[j][0] = t.x; bv[j][1] = t.y; bv[j][2] = t.z; bv[j][3] = t.w;
         } else {
 #pragma unroll
@@ -576,11 +579,32 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][kk], bv[j][kk], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NT; ++j) {
+            if (DBG & 2) acc[i][j][kk] += av[i][kk] * bv[j][kk];   // timing-only build: no MFMA
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][kk], bv[j][kk], acc[i][j], 0, 0, 0);
+          }
     }
-    store_chunk(cur ^ 1);
-    __syncthreads();
+  };
+
+  // Software pipeline, two chunks of global loads in flight: while chunk c is multiplied out of LDS,
+  // chunk c+1 sits in registers (issued one iteration earlier) and chunk c+2 is being issued.  Loads
+  // past the end have every offset out of range (zeros, never read).  One barrier per chunk.
+  Stage s0, s1;
+  load_chunk(s0, c_begin, c_begin < c_end);
+  store_chunk(s0, 0);
+  load_chunk(s0, c_begin + 1, c_begin + 1 < c_end);
+  __syncthreads();
+  for (int c = c_begin; c < c_end; c += 2) {
+    if (!(DBG & 1)) load_chunk(s1, c + 2, c + 2 < c_end);
+    compute(0);
+    if (!(DBG & 8)) store_chunk(s0, 1);
+    if (!(DBG & 4)) __syncthreads();
+    // (an odd chunk count multiplies one extra all-zero chunk: cheaper than a second loop exit,
+    //  which makes hipcc keep two copies of the accumulators)
+    if (!(DBG & 1)) load_chunk(s0, c + 3, c + 3 < c_end);
+    compute(1);
+    if (!(DBG & 8)) store_chunk(s1, 0);
+    if (!(DBG & 4)) __syncthreads();
   }
   gg_epilogue<BM, BN, WM, WN>(p, acc, s_off, As, m0, n0);
 }
@@ -626,29 +650,60 @@ int veex_gg_m_tiles(GGParams& p) {
   return t;
 }
 
-template <int BM, int BN, bool MODE1>
+template <int BM, int BN, bool MODE1, int BK>
 static constexpr size_t gg_lds_bytes() {
-  return (2 * BM * VEEX_LDK + 2 * (MODE1 ? BN * VEEX_LDK : VEEX_BK * (BN + 4))) * sizeof(float) + BM * sizeof(int);
+  return (2 * BM * (BK + 4) + 2 * (MODE1 ? BN * (BK + 4) : BK * (BN + 4))) * sizeof(float) + BM * sizeof(int);
 }
 
-template <int BM, int BN, bool MODE1>
+template <typename K>
+static int gg_set_lds(K kernel, size_t lds) {
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      veex_set_error("gather_gemm: cannot raise the dynamic LDS limit to %zu bytes", lds);
+      return -3;
+    }
+  }
+  return 0;
+}
+
+template <int BM, int BN, bool MODE1, int BK>
 static int gg_launch_fast(const GGParams& p, dim3 grid, hipStream_t st) {
-  constexpr size_t lds = gg_lds_bytes<BM, BN, MODE1>();
+  constexpr size_t lds = gg_lds_bytes<BM, BN, MODE1, BK>();
   const int aff = (p.a_scale == nullptr) ? 0 : (p.aff_spatial ? 2 : 1);
-  if (aff == 0) hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 2, 2, MODE1, 0>), grid, dim3(256), lds, st, p);
-  else if (aff == 1) hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 2, 2, MODE1, 1>), grid, dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 2, 2, MODE1, 2>), grid, dim3(256), lds, st, p);
+  static bool attr_done = false;   // function attributes are per process; set them once, outside any capture
+  if (!attr_done) {
+    if (gg_set_lds(gather_gemm_kernel<BM, BN, 2, 2, MODE1, 0, BK>, lds) || gg_set_lds(gather_gemm_kernel<BM, BN, 2, 2, MODE1, 1, BK>, lds) ||
+        gg_set_lds(gather_gemm_kernel<BM, BN, 2, 2, MODE1, 2, BK>, lds)) return -3;
+    attr_done = true;
+  }
+  if (aff == 0) hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 2, 2, MODE1, 0, BK>), grid, dim3(256), lds, st, p);
+  else if (aff == 1) hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 2, 2, MODE1, 1, BK>), grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 2, 2, MODE1, 2, BK>), grid, dim3(256), lds, st, p);
   VEEX_CHECK_LAUNCH();
   return 0;
 }
 
 template <int BM, int BN>
-static int gg_launch_cfg(const GGParams& p, int mtiles, bool fast, hipStream_t st) {
+static int gg_launch_cfg(GGParams& p, int mtiles, bool fast, hipStream_t st) {
   const int ntiles = (p.Cout + BN - 1) / BN;
   dim3 grid(mtiles, ntiles, p.nsplit);
-  if (fast) return (p.mode == 1) ? gg_launch_fast<BM, BN, true>(p, grid, st) : gg_launch_fast<BM, BN, false>(p, grid, st);
-  constexpr size_t lds1 = gg_lds_bytes<BM, BN, true>();
-  constexpr size_t lds0 = gg_lds_bytes<BM, BN, false>();
+  if (fast) {
+    static const int want32 = [] { const char* e = getenv("VEEX_BK"); return (e != nullptr && atoi(e) == 32) ? 1 : 0; }();
+    const bool bk32 = want32 && ((p.kh * p.kw == 1) || (p.Cin % 32 == 0));
+    const int bk = bk32 ? 32 : 16;
+    if (p.nsplit > 1) {
+      const int nchunks = p.kh * p.kw * ((p.Cin + bk - 1) / bk);
+      p.chunks_per_split = (nchunks + p.nsplit - 1) / p.nsplit;
+    }
+    if (bk32) return (p.mode == 1) ? gg_launch_fast<BM, BN, true, 32>(p, grid, st) : gg_launch_fast<BM, BN, false, 32>(p, grid, st);
+    return (p.mode == 1) ? gg_launch_fast<BM, BN, true, 16>(p, grid, st) : gg_launch_fast<BM, BN, false, 16>(p, grid, st);
+  }
+  if (p.nsplit > 1) {
+    const int nchunks = p.kh * p.kw * ((p.Cin + VEEX_BK - 1) / VEEX_BK);
+    p.chunks_per_split = (nchunks + p.nsplit - 1) / p.nsplit;
+  }
+  constexpr size_t lds1 = gg_lds_bytes<BM, BN, true, VEEX_BK>();
+  constexpr size_t lds0 = gg_lds_bytes<BM, BN, false, VEEX_BK>();
   if (p.mode == 1)
     hipLaunchKernelGGL((gather_gemm_generic_kernel<BM, BN, 2, 2, true>), grid, dim3(256), lds1, st, p);
   else
@@ -665,7 +720,7 @@ int veex_launch_gather_gemm(const GGParams& pin, hipStream_t st) {
   }
   if (p.kh * p.kw > 1 && (p.Cin % VEEX_BK) != 0) {
     veex_set_error("gather_gemm: multi-tap layers need Cin %% 16 == 0 (got %d)", p.Cin); return -1;
-  }
+  }  // (the K chunk is 32 when Cin %% 32 == 0 or the layer has a single tap, else 16)
   if (p.a_scale && ((p.aff_mask + 1) & p.aff_mask)) { veex_set_error("gather_gemm: affine size must be a power of two"); return -1; }
   const long long Mtot = (long long)p.Nb * p.Hout * p.Wout;
   if (Mtot * p.Cout >= (1LL << 40) || Mtot >= (1LL << 31)) { veex_set_error("gather_gemm: problem too large"); return -1; }
@@ -694,4 +749,65 @@ int veex_launch_gather_gemm(const GGParams& pin, hipStream_t st) {
     return -1;
   }
   return gg_launch_cfg<64, 64>(p, mtiles, false, st);
+}
+
+// Timing-only variants for profiling (outputs are wrong by construction): dbg 1 = no global loads in the
+// K loop, dbg 2 = no MFMA.  Only the 128x64 mode-1 per-channel-affine and 128x128 mode-0 no-affine shapes.
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float a = threadIdx.x * 1e-3f, b = blockIdx.x * 1e-3f + 1.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// returns nothing useful in out; flops = grid*4 waves*iters*32 MFMAs*4096
+extern "C" int veexi_debug_mfma_peak(float* out, int blocks, int iters, hipStream_t st) {
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st, out, iters);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+#define DBG_CASE(BM_, BN_, M1_, AFF_, D_) \
+  case D_: hipLaunchKernelGGL((gather_gemm_kernel<BM_, BN_, 2, 2, M1_, AFF_, 32, D_>), grid, dim3(256), lds, st, p); break;
+
+// Timing-only variants for profiling (outputs are wrong by construction). dbg bits: 1 = no global loads in
+// the K loop, 2 = no MFMA, 4 = no barrier, 8 = no LDS store.
+extern "C" int veexi_debug_gather_gemm(const GGParams* pin, int dbg, hipStream_t st) {
+  GGParams p = *pin;
+  const int mtiles = veex_gg_m_tiles(p);
+  p.nsplit = 1; p.chunks_per_split = 1 << 30;
+  if (p.mode == 1 && p.Cout <= 64) {
+    dim3 grid(mtiles, 1, 1);
+    constexpr size_t lds = gg_lds_bytes<128, 64, true, 32>();
+    switch (dbg) {
+      DBG_CASE(128, 64, true, 1, 0) DBG_CASE(128, 64, true, 1, 1) DBG_CASE(128, 64, true, 1, 2)
+      DBG_CASE(128, 64, true, 1, 5) DBG_CASE(128, 64, true, 1, 9) DBG_CASE(128, 64, true, 1, 13)
+      default: return -1;
+    }
+  } else {
+    dim3 grid(mtiles, (p.Cout + 127) / 128, 1);
+    constexpr size_t lds = gg_lds_bytes<128, 128, false, 32>();
+    static bool done = false;
+    if (!done) {
+      gg_set_lds(gather_gemm_kernel<128, 128, 2, 2, false, 0, 32, 0>, lds); gg_set_lds(gather_gemm_kernel<128, 128, 2, 2, false, 0, 32, 1>, lds);
+      gg_set_lds(gather_gemm_kernel<128, 128, 2, 2, false, 0, 32, 2>, lds); gg_set_lds(gather_gemm_kernel<128, 128, 2, 2, false, 0, 32, 5>, lds);
+      gg_set_lds(gather_gemm_kernel<128, 128, 2, 2, false, 0, 32, 9>, lds); gg_set_lds(gather_gemm_kernel<128, 128, 2, 2, false, 0, 32, 13>, lds);
+      done = true;
+    }
+    switch (dbg) {
+      DBG_CASE(128, 128, false, 0, 0) DBG_CASE(128, 128, false, 0, 1) DBG_CASE(128, 128, false, 0, 2)
+      DBG_CASE(128, 128, false, 0, 5) DBG_CASE(128, 128, false, 0, 9) DBG_CASE(128, 128, false, 0, 13)
+      default: return -1;
+    }
+  }
+  VEEX_CHECK_LAUNCH();
+  return 0;
 }

@@ -1,5 +1,161 @@
-"""Live roofline measurement of the dominant kernel (filled in after profiling)."""
+"""Per-kernel timing of the hot path's GEMM launches through the operator-level C-ABI, with HIP
+events on the launch stream, and the roofline arithmetic bench.py reports (Measurement).
+
+Algorithmic work of one launch = exact in-bounds MACs of SURVEY 8a (x batch) for the layer; the
+bound for every conv / deconv / dense contraction in fp32 is the f32 MFMA peak (157.3 TFLOP/s,
+MI355X_MICROARCH.md); the HBM-bound kernels are priced in bytes against 8 TB/s.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import lib, check, GemmDesc, WgradDesc
+
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+# (name, Cin, Cout, k, stride, pad_begin, Hin, Hout, exact forward MACs per sample [SURVEY 8a])
+CONVS = [
+    ("enc.conv2", 64, 128, 3, 2, 0, 20, 10, 6_889_472),
+    ("enc.conv3", 128, 256, 3, 2, 0, 10, 5, 6_422_528),
+]
+DECONVS = [
+    ("dec.deconv1", 256, 256, 3, 2, 0, 4, 8, 7_929_856),
+    ("dec.deconv2", 256, 128, 3, 1, 1, 8, 8, 15_859_712),
+    ("dec.deconv3", 128, 128, 3, 2, 0, 8, 17, 9_437_184),
+    ("dec.deconv4", 128, 64, 3, 1, 0, 17, 19, 21_307_392),
+    ("dec.deconv5", 64, 64, 3, 2, 0, 19, 39, 13_307_904),
+]
+
+
+def _time_launch(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        fn()
+    e1.record(st)
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters     # seconds per launch
+
+
+def _rand(*shape):
+    return torch.rand(*shape, device="cuda", dtype=torch.float32) - 0.5
+
+
+def gemm_cases(B):
+    """Yield (label, macs, launch_fn) for every MFMA launch of one train step at batch B."""
+    stream = _lib.current_stream
+    keep = []
+
+    def gg(label, macs, mode, A, W, out, N, Hin, Cin, Hout, Cout, k, stride, pb, aff=None, spatial=0, epi=0,
+           aux=None, esc=None):
+        d = GemmDesc()
+        d.inp, d.weight, d.out = A.data_ptr(), W.data_ptr(), out.data_ptr()
+        if aff is not None:
+            d.in_scale, d.in_shift, d.affine_channels, d.affine_spatial = aff[0].data_ptr(), aff[1].data_ptr(), aff[0].numel(), spatial
+        if epi == 0:
+            bias = _rand(Cout); keep.append(bias); d.bias = bias.data_ptr(); d.relu = 1
+        else:
+            d.aux, d.relu = aux.data_ptr(), 1
+            if esc is not None:
+                d.e_scale, d.e_channels = esc.data_ptr(), esc.numel()
+            mt = None
+        d.N, d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.Cout = N, Hin, Hin, Cin, Hout, Hout, Cout
+        d.kh = d.kw = k
+        d.stride, d.pad_begin, d.mode, d.epilogue, d.nsplit = stride, pb, mode, epi, 1
+        if epi == 1:
+            mt = lib.veex_gather_gemm_m_tiles(C.byref(d))
+            part = torch.empty(mt * 3 * Cout, device="cuda"); keep.append(part); d.partials = part.data_ptr()
+        keep.extend([A, W, out, d])
+        return label, macs, (lambda d=d: check(lib.veex_gather_gemm(C.byref(d), stream()), label))
+
+    def wg(label, macs, big, small, N, Hb, Cb, Hs, Cs, k, stride, pb, aff_small=None, aff_big=None):
+        d = WgradDesc()
+        d.big, d.small = big.data_ptr(), small.data_ptr()
+        if aff_small is not None:
+            d.small_scale, d.small_shift, d.small_affine_channels = aff_small[0].data_ptr(), aff_small[1].data_ptr(), aff_small[0].numel()
+        if aff_big is not None:
+            d.big_scale, d.big_shift, d.big_affine_channels = aff_big[0].data_ptr(), aff_big[1].data_ptr(), aff_big[0].numel()
+        d.N, d.Hb, d.Wb, d.Cb, d.Hs, d.Ws, d.Cs = N, Hb, Hb, Cb, Hs, Hs, Cs
+        d.kh = d.kw = k
+        d.stride, d.pad_begin = stride, pb
+        R = N * Hs * Hs
+        M = k * k * Cb
+        tiles = ((M + 127) // 128) * ((Cs + 127) // 128 if Cs > 64 else 1)
+        chunks = (R + 15) // 16
+        ns = max(1, min((768 + tiles - 1) // tiles, max(chunks // 4, 1)))
+        cps = (chunks + ns - 1) // ns
+        d.rows_per_split = cps * 16
+        d.nsplit = (R + d.rows_per_split - 1) // d.rows_per_split
+        out = torch.empty(d.nsplit * M * Cs, device="cuda")
+        d.out = out.data_ptr()
+        keep.extend([big, small, out, d])
+        return label, macs, (lambda d=d: check(lib.veex_wgrad_gemm(C.byref(d), stream()), label))
+
+    cases = []
+    for name, cin, cout, k, s, pb, hin, hout, macs in CONVS:
+        x = _rand(B, hin, hin, cin); y = torch.empty(B, hout, hout, cout, device="cuda")
+        W = _rand(k, k, cin, cout) * 0.1
+        aff = (torch.rand(cin, device="cuda") + 0.5, _rand(cin))
+        dy = _rand(B, hout, hout, cout); dx = torch.empty_like(x)
+        cases.append(gg(f"{name}.fwd", macs * B, 0, x, W, y, B, hin, cin, hout, cout, k, s, pb, aff=aff))
+        cases.append(gg(f"{name}.dgrad", macs * B, 1, dy, W, dx, B, hout, cout, hin, cin, k, s, pb, epi=1, aux=x,
+                        esc=aff[0]))
+        cases.append(wg(f"{name}.wgrad", macs * B, x, dy, B, hin, cin, hout, cout, k, s, pb, aff_big=aff))
+    for name, cin, cout, k, s, pb, hin, hout, macs in DECONVS:
+        x = _rand(B, hin, hin, cin); y = torch.empty(B, hout, hout, cout, device="cuda")
+        W = _rand(k, k, cout, cin) * 0.1
+        spatial = 1 if name == "dec.deconv1" else 0
+        nch = hin * hin * cin if spatial else cin
+        aff = (torch.rand(nch, device="cuda") + 0.5, _rand(nch))
+        dy = _rand(B, hout, hout, cout); dx = torch.empty_like(x)
+        cases.append(gg(f"{name}.fwd", macs * B, 1, x, W, y, B, hin, cin, hout, cout, k, s, pb, aff=aff, spatial=spatial))
+        if spatial:
+            cases.append(gg(f"{name}.dgrad", macs * B, 0, dy, W, dx, B, hout, cout, hin, cin, k, s, pb))
+        else:
+            cases.append(gg(f"{name}.dgrad", macs * B, 0, dy, W, dx, B, hout, cout, hin, cin, k, s, pb, epi=1, aux=x,
+                            esc=aff[0]))
+        if not spatial:
+            cases.append(wg(f"{name}.wgrad", macs * B, dy, x, B, hout, cout, hin, cin, k, s, pb, aff_small=aff))
+    gemm_cases._keep = keep
+    return cases
+
+
+def layer_table(B=512, iters=10):
+    rows = []
+    for label, macs, fn in gemm_cases(B):
+        t = _time_launch(fn, iters)
+        tf = 2.0 * macs / t / 1e12
+        rows.append({"kernel": label, "us": t * 1e6, "tflops": tf, "frac": tf / PEAK_F32_MFMA_TFLOPS})
+    return rows
 
 
 def dominant_kernel_roofline(net, batch):
-    return None
+    """The MFMA launch with the largest share of the step (dec.deconv4 forward: the largest-FLOP
+    layer), timed live with HIP events on the launch stream."""
+    best = None
+    for label, macs, fn in gemm_cases(batch):
+        if label != "dec.deconv4.fwd":
+            continue
+        t = _time_launch(fn, iters=20, warm=3)
+        tf = 2.0 * macs / t / 1e12
+        best = {"bound": "mfma", "kernel": "gather_gemm_kernel<128,64,mode1> (dec.deconv4 forward, Conv2DTranspose 128->64 k3 s1)",
+                "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
+                "traffic": None, "us_per_launch": t * 1e6, "algorithmic_flop_per_launch": 2.0 * macs}
+    return best
+
+
+if __name__ == "__main__":
+    import sys
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    tot = 0.0
+    for r in layer_table(B):
+        tot += r["us"]
+        print(f"{r['kernel']:22s} {r['us']:8.1f} us  {r['tflops']:6.1f} TF  {100 * r['frac']:5.1f}% of f32 MFMA peak")
+    print(f"sum {tot:.1f} us")
