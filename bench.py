@@ -54,7 +54,7 @@ def synth(n, seed=1234):
     return out
 
 
-def cpu_baseline(seconds_budget=20.0):
+def cpu_baseline(seconds_budget=15.0):
     """config[0] on the host cores: the torch-CPU restatement (oracle/torch_ref.py, fp32, oneDNN)
     of the reference train step, batch 64 -- kind 'port' (TensorFlow is not installable here)."""
     import torch
@@ -72,7 +72,7 @@ def cpu_baseline(seconds_budget=20.0):
         tr.train_step(xb)
         n_done += xb.shape[0]
         i += 1
-        if time.perf_counter() - t0 > seconds_budget or i >= 64:
+        if time.perf_counter() - t0 > seconds_budget or i >= 2000:
             break
     dt = time.perf_counter() - t0
     return {"value": n_done / dt, "unit": "samples/s", "cores": cores, "kind": "port",

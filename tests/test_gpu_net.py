@@ -168,10 +168,14 @@ def test_three_training_steps_track_the_oracle():
     pp = {k: a.copy() for k, a in p.items()}
     lr = 1e-5                                     # the reference's learning rate (train.py:106)
     for t in range(1, 4):
-        ref_loss = vo.train_step(pp, m, v, t, lr, x, eps)[0]
+        # the oracle's step, evaluated at the device's ReLU decisions (they differ only at fp32 kinks,
+        # which device_masks asserts); without this a single flipped kink moves a conv1 gradient by ~1e-4
+        c = vo.forward(pp, x, eps, "vae")
         loss = float(net.train_fwd_bwd(x, eps).cpu()[0])
+        g = vo.backward(pp, c, "vae", device_masks(net, B, c))
+        vo.adam_step(pp, {k: g[k] for k in names}, m, v, t, lr)
         net.adam_step(lr)
-        assert abs(loss - ref_loss) < RTOL * abs(ref_loss)
+        assert abs(loss - c["total"]) < RTOL * abs(c["total"])
     w = net.get_weights_dict()
     mm = net.get_weights_dict(net.adam_m)
     for k in names:

@@ -12,7 +12,7 @@ class GGParams(C.Structure):
                 ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int), ("pb", C.c_int), ("mode", C.c_int),
                 ("aff_mask", C.c_int), ("aff_spatial", C.c_int), ("epi", C.c_int), ("relu", C.c_int), ("epi_cmask", C.c_int),
                 ("nsplit", C.c_int), ("chunks_per_split", C.c_int), ("nphase", C.c_int), ("tile_prefix", C.c_int * 5),
-                ("Hp", C.c_int * 2), ("Wp", C.c_int * 2), ("o0", C.c_int * 2), ("slab_stride", C.c_longlong)]
+                ("Hp", C.c_int * 2), ("Wp", C.c_int * 2), ("o0", C.c_int * 2), ("slab_stride", C.c_longlong), ("gx", C.c_int), ("gy", C.c_int), ("gz", C.c_int), ("remap", C.c_int), ("tap_inner", C.c_int)]
 
 raw = C.CDLL(_lib.LIB_PATH)
 fn = raw.veexi_debug_gather_gemm
@@ -30,13 +30,11 @@ def case(mode, hin, cin, hout, cout, k, s, pb, aff):
     keep = (x, y, W, bias, sc, sh)
     return p, keep
 for label, args in [("deconv4.fwd  Cin=128 (mode1 128x64 aff)", (1, 17, 128, 19, 64, 3, 1, 0, True)),
-                    ("deconv4.fwd  Cin=256 (mode1 128x64 aff)", (1, 17, 256, 19, 64, 3, 1, 0, True)),
-                    ("deconv4.dgrad Cin=64 (mode0 128x128)   ", (0, 19, 64, 17, 128, 3, 1, 0, False)),
-                    ("deconv4.dgrad Cin=128(mode0 128x128)   ", (0, 19, 128, 17, 128, 3, 1, 0, False))]:
+                    ("deconv4.fwd  Cin=256 (mode1 128x64 aff)", (1, 17, 256, 19, 64, 3, 1, 0, True))]:
     p, keep = case(*args)
-    for dbg, nm in [(0, "full"), (1, "no-gload"), (13, "mfma+ldsread only")]:
+    for dbg, nm in [(0, "full"), (16, "no-epilogue"), (1, "no-gload"), (13, "mfma+ldsread only"), (29, "mfma+ldsread, no-epilogue")]:
         t = _time_launch(lambda: fn(C.byref(p), dbg, _lib.current_stream()), iters=10)
-        print(f"{label} {nm:16s} {t*1e6:8.1f} us")
+        print(f"{label} {nm:26s} {t*1e6:8.1f} us")
 pk = raw.veexi_debug_mfma_peak; pk.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]; pk.restype = C.c_int
 out = torch.empty(4096 * 256, device="cuda")
 for blocks in (256, 512, 768):

@@ -19,6 +19,7 @@
 // dbeta, dbias);  RAW = split-K partial slab.
 #include "veex_internal.h"
 #include <stdlib.h>
+#include <algorithm>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -40,21 +41,20 @@ __device__ __forceinline__ float4 ld4(const float* ptr, bool ok, int nvalid, boo
 // Shared epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
-                                            const int* s_off, float* As, int m0, int n0) {
+                                            const int* s_off, float* As, int tile, int kz, int n0) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 32, NT = WTN / 32;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int lh = lane >> 5, l31 = lane & 31;
-  (void)m0;
   // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float cs1[NT], cs2[NT], cs3[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) { cs1[j] = 0.f; cs2[j] = 0.f; cs3[j] = 0.f; }
 
   float* outp = p.Out;
-  if (p.epi == VEEX_EPI_RAW) outp += (long long)blockIdx.z * p.slab_stride;
+  if (p.epi == VEEX_EPI_RAW) outp += (long long)kz * p.slab_stride;
 
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -116,7 +116,7 @@ __device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[BM 
         t2 += s_red[(w * BN + tid) * 3 + 1];
         t3 += s_red[(w * BN + tid) * 3 + 2];
       }
-      float* pp = p.partials + (long long)blockIdx.x * 3 * p.Cout + n0 + tid;
+      float* pp = p.partials + (long long)tile * 3 * p.Cout + n0 + tid;
       pp[0] = t1;
       pp[p.Cout] = t2;
       pp[2 * p.Cout] = t3;
@@ -147,8 +147,12 @@ __global__ __launch_bounds__(256) void gather_gemm_generic_kernel(const GGParams
   const int lh = lane >> 5, l31 = lane & 31;
 
   // ---- block -> (phase, m tile, n tile, k split) ----
-  int tile = blockIdx.x, ph = 0;
+  int bnt, btile, kz;
+  veex_block_coords(p.remap, p.gx, p.gy, bnt, btile, kz);
+  int tile = btile, ph = 0;
   if (p.nphase == 4) {
+    // phases are concatenated, 4-tap phase first: the heavy tiles start first and the 1-tap tiles
+    // fill the tail (interleaving the phases measured 5-18 % slower)
     while (ph < 3 && tile >= p.tile_prefix[ph + 1]) ++ph;
   }
   const int py = ph >> 1, px = ph & 1;
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256) void gather_gemm_generic_kernel(const GGParams
   const int oy0 = p.o0[py], ox0 = p.o0[px];
   const int Mph = p.Nb * Hp * Wp;
   const int m0 = (tile - p.tile_prefix[ph]) * BM;
-  const int n0 = blockIdx.y * BN;
+  const int n0 = bnt * BN;
 
   int kys = 0, kxs = 0, kstep = 1, nky = p.kh, nkx = p.kw;
   if (p.nphase == 4) {
@@ -166,8 +170,9 @@ __global__ __launch_bounds__(256) void gather_gemm_generic_kernel(const GGParams
     nkx = (p.kw - px + 1) >> 1;
   }
   const int cpt = (p.Cin + VEEX_BK - 1) / VEEX_BK;
-  const int nchunks = nky * nkx * cpt;
-  const int c_begin = blockIdx.z * p.chunks_per_split;
+  const int ntaps = nky * nkx;
+  const int nchunks = ntaps * cpt;
+  const int c_begin = kz * p.chunks_per_split;
   const int c_end = min(nchunks, c_begin + p.chunks_per_split);
 
   const int HWp = Hp * Wp;
@@ -205,8 +210,10 @@ __global__ __launch_bounds__(256) void gather_gemm_generic_kernel(const GGParams
   float4 ra[APASS], rb[BPASS];
 
   auto load_chunk = [&](int c) {
-    const int tapi = c / cpt;
-    const int cc = c - tapi * cpt;
+    // tap_inner: channel chunk outer, tap inner -- the shifted re-reads of one channel slice follow
+    // each other closely (L2 hits instead of Infinity-Cache / HBM re-fetches)
+    const int cc = p.tap_inner ? c / ntaps : c % cpt;
+    const int tapi = p.tap_inner ? c - cc * ntaps : c / cpt;
     const int ia = tapi / nkx, ib = tapi - ia * nkx;
     const int ky = kys + kstep * ia, kx = kxs + kstep * ib;
     const int tap = ky * p.kw + kx;
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(256) void gather_gemm_generic_kernel(const GGParams
     __syncthreads();
   }
 
-  gg_epilogue<BM, BN, WM, WN>(p, acc, s_off, As, m0, n0);
+  gg_epilogue<BM, BN, WM, WN>(p, acc, s_off, As, btile, kz, n0);
 }
 
 
@@ -384,8 +391,12 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
   const int wm = wave / WN, wn = wave % WN;
   const int lh = lane >> 5, l31 = lane & 31;
 
-  int tile = blockIdx.x, ph = 0;
+  int bnt, btile, kz;
+  veex_block_coords(p.remap, p.gx, p.gy, bnt, btile, kz);
+  int tile = btile, ph = 0;
   if (p.nphase == 4) {
+    // phases are concatenated, 4-tap phase first: the heavy tiles start first and the 1-tap tiles
+    // fill the tail (interleaving the phases measured 5-18 % slower)
     while (ph < 3 && tile >= p.tile_prefix[ph + 1]) ++ph;
   }
   const int py = ph >> 1, px = ph & 1;
@@ -394,7 +405,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
   const int oy0 = p.o0[py], ox0 = p.o0[px];
   const int Mph = p.Nb * Hp * Wp;
   const int m0 = (tile - p.tile_prefix[ph]) * BM;
-  const int n0 = blockIdx.y * BN;
+  const int n0 = bnt * BN;
 
   int kys = 0, kxs = 0, kstep = 1, nky = p.kh, nkx = p.kw;
   if (p.nphase == 4) {
@@ -403,9 +414,10 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
     nkx = (p.kw - px + 1) >> 1;
   }
   const int cpt = (p.Cin + BK - 1) / BK;
-  const int nchunks = nky * nkx * cpt;
-  const int c_begin = blockIdx.z * p.chunks_per_split;
-  const int c_end = min(nchunks, c_begin + p.chunks_per_split);
+  const int ntaps = nky * nkx;
+  const int nchunks = ntaps * cpt;
+  const int c_begin = kz * p.chunks_per_split;
+  const int c_end = (DBG & 32) ? c_begin : min(nchunks, c_begin + p.chunks_per_split);
   const int HWp = Hp * Wp;
 
   if (tid < BM) {
@@ -481,8 +493,8 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
   };
 
   auto load_chunk = [&](Stage& st, int c, bool cvalid) {
-    const int tapi = c / cpt;
-    const int cc = c - tapi * cpt;
+    const int cc = p.tap_inner ? c / ntaps : c % cpt;   // see the generic kernel
+    const int tapi = p.tap_inner ? c - cc * ntaps : c / cpt;
     const int ia = tapi / nkx, ib = tapi - ia * nkx;
     const int tap = (kys + kstep * ia) * p.kw + (kxs + kstep * ib);
     const int ci0 = cc * BK;
@@ -606,7 +618,18 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
     if (!(DBG & 8)) store_chunk(s1, 0);
     if (!(DBG & 4)) __syncthreads();
   }
-  gg_epilogue<BM, BN, WM, WN>(p, acc, s_off, As, m0, n0);
+  if (DBG & 16) {   // timing-only: one store per thread keeps the accumulators alive
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int jj = 0; jj < NT; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[i][jj][r];
+    p.Out[(long long)btile * 256 + tid] = t;
+    return;
+  }
+  gg_epilogue<BM, BN, WM, WN>(p, acc, s_off, As, btile, kz, n0);
 }
 
 // ---------------------------------------------------------------------------
@@ -686,7 +709,13 @@ static int gg_launch_fast(const GGParams& p, dim3 grid, hipStream_t st) {
 template <int BM, int BN>
 static int gg_launch_cfg(GGParams& p, int mtiles, bool fast, hipStream_t st) {
   const int ntiles = (p.Cout + BN - 1) / BN;
-  dim3 grid(mtiles, ntiles, p.nsplit);
+  // XCD-contiguous block order: neutral on single-phase layers, but on the 4-phase (stride-2 deconv)
+  // launches whole XCDs would get only 4-tap or only 1-tap tiles (+30..50 % time): round-robin there
+  const int xr = veex_env_int("VEEX_XCD", -1);
+  p.remap = (xr < 0) ? (p.nphase == 1) : xr;
+  p.tap_inner = veex_env_int("VEEX_TAPIN", 1);   // measured -1..-4 % on every layer
+  p.gx = ntiles; p.gy = mtiles; p.gz = p.nsplit;
+  dim3 grid((unsigned)ntiles * mtiles * p.nsplit, 1, 1);
   if (fast) {
     static const int want32 = [] { const char* e = getenv("VEEX_BK"); return (e != nullptr && atoi(e) == 32) ? 1 : 0; }();
     const bool bk32 = want32 && ((p.kh * p.kw == 1) || (p.Cin % 32 == 0));
@@ -776,7 +805,7 @@ extern "C" int veexi_debug_mfma_peak(float* out, int blocks, int iters, hipStrea
 }
 
 #define DBG_CASE(BM_, BN_, M1_, AFF_, D_) \
-  case D_: hipLaunchKernelGGL((gather_gemm_kernel<BM_, BN_, 2, 2, M1_, AFF_, 32, D_>), grid, dim3(256), lds, st, p); break;
+  case D_: hipLaunchKernelGGL((gather_gemm_kernel<BM_, BN_, 2, 2, M1_, AFF_, 16, D_>), grid, dim3(256), lds, st, p); break;
 
 // Timing-only variants for profiling (outputs are wrong by construction). dbg bits: 1 = no global loads in
 // the K loop, 2 = no MFMA, 4 = no barrier, 8 = no LDS store.
@@ -785,21 +814,24 @@ extern "C" int veexi_debug_gather_gemm(const GGParams* pin, int dbg, hipStream_t
   const int mtiles = veex_gg_m_tiles(p);
   p.nsplit = 1; p.chunks_per_split = 1 << 30;
   if (p.mode == 1 && p.Cout <= 64) {
+    p.gx = 1; p.gy = mtiles; p.gz = 1; p.remap = veex_env_int("VEEX_XCD", 1); p.tap_inner = veex_env_int("VEEX_TAPIN", 1);
     dim3 grid(mtiles, 1, 1);
-    constexpr size_t lds = gg_lds_bytes<128, 64, true, 32>();
+    constexpr size_t lds = gg_lds_bytes<128, 64, true, 16>();
     switch (dbg) {
       DBG_CASE(128, 64, true, 1, 0) DBG_CASE(128, 64, true, 1, 1) DBG_CASE(128, 64, true, 1, 2)
       DBG_CASE(128, 64, true, 1, 5) DBG_CASE(128, 64, true, 1, 9) DBG_CASE(128, 64, true, 1, 13)
+      DBG_CASE(128, 64, true, 1, 16) DBG_CASE(128, 64, true, 1, 32) DBG_CASE(128, 64, true, 1, 48) DBG_CASE(128, 64, true, 1, 29)
       default: return -1;
     }
   } else {
-    dim3 grid(mtiles, (p.Cout + 127) / 128, 1);
-    constexpr size_t lds = gg_lds_bytes<128, 128, false, 32>();
+    p.gx = (p.Cout + 127) / 128; p.gy = mtiles; p.gz = 1; p.remap = veex_env_int("VEEX_XCD", 1); p.tap_inner = veex_env_int("VEEX_TAPIN", 1);
+    dim3 grid(mtiles * p.gx, 1, 1);
+    constexpr size_t lds = gg_lds_bytes<128, 128, false, 16>();
     static bool done = false;
     if (!done) {
-      gg_set_lds(gather_gemm_kernel<128, 128, 2, 2, false, 0, 32, 0>, lds); gg_set_lds(gather_gemm_kernel<128, 128, 2, 2, false, 0, 32, 1>, lds);
-      gg_set_lds(gather_gemm_kernel<128, 128, 2, 2, false, 0, 32, 2>, lds); gg_set_lds(gather_gemm_kernel<128, 128, 2, 2, false, 0, 32, 5>, lds);
-      gg_set_lds(gather_gemm_kernel<128, 128, 2, 2, false, 0, 32, 9>, lds); gg_set_lds(gather_gemm_kernel<128, 128, 2, 2, false, 0, 32, 13>, lds);
+      gg_set_lds(gather_gemm_kernel<128, 128, 2, 2, false, 0, 16, 0>, lds); gg_set_lds(gather_gemm_kernel<128, 128, 2, 2, false, 0, 16, 1>, lds);
+      gg_set_lds(gather_gemm_kernel<128, 128, 2, 2, false, 0, 16, 2>, lds); gg_set_lds(gather_gemm_kernel<128, 128, 2, 2, false, 0, 16, 5>, lds);
+      gg_set_lds(gather_gemm_kernel<128, 128, 2, 2, false, 0, 16, 9>, lds); gg_set_lds(gather_gemm_kernel<128, 128, 2, 2, false, 0, 16, 13>, lds);
       done = true;
     }
     switch (dbg) {

@@ -7,6 +7,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -22,6 +23,12 @@ void veex_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* veex_last_error(void) { return g_err; }
+
+// tuning switches from the environment (read on every call: a handful of getenv per step)
+int veex_env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e != nullptr && *e) ? atoi(e) : dflt;
+}
 extern "C" int veex_abi_version(void) { return 1; }
 
 extern "C" int veexi_loss_finalize(const float*, const float*, const float*, int, float*, float*, float*, hipStream_t);

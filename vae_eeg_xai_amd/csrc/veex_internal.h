@@ -38,6 +38,9 @@ struct GGParams {
   int Hp[2], Wp[2];      // rows / cols of each parity class (nphase==1: Hp[0]=Hout, Wp[0]=Wout)
   int o0[2];             // first output coordinate of parity class p
   long long slab_stride; // elements per split slab (RAW)
+  int gx, gy, gz;        // logical grid (n tiles, m tiles, k splits), filled by the launcher
+  int remap;             // 1: XCD-aware block order (veex_block_coords)
+  int tap_inner;         // K-chunk order: 1 = channel chunk outer / tap inner, 0 = tap outer
 };
 
 // ---------------------------------------------------------------------------
@@ -57,7 +60,28 @@ struct WGParams {
   int rows_per_split;    // multiple of VEEX_BK
   int M;                 // kh*kw*Cb
   int nsplit;
+  int gx, gy, gz;        // logical grid (m tiles, n tiles, row splits), filled by the launcher
+  int remap;
 };
+
+// Logical block coordinates of a 1-D launch, XCD-aware: workgroups are placed round-robin over the
+// 8 XCDs (linear id % 8), each with its own 4 MiB L2, so CONSECUTIVE logical blocks -- which share
+// operand tiles (the same rows for every n tile / tap tile, halo rows between neighbouring m tiles)
+// -- are mapped onto ONE XCD and dispatched close in time.  Speed only: any placement is correct.
+#ifdef __HIPCC__
+__device__ __forceinline__ void veex_block_coords(int remap, int gx, int gy, int& bx, int& by, int& bz) {
+  const unsigned total = gridDim.x, lin = blockIdx.x;
+  const unsigned xcd = lin & 7u, local = lin >> 3;
+  const unsigned q = total >> 3, r = total & 7u;
+  const unsigned logical = remap ? xcd * q + (xcd < r ? xcd : r) + local : lin;
+  const unsigned t = logical / (unsigned)gx;
+  bx = (int)(logical - t * (unsigned)gx);
+  bz = (int)(t / (unsigned)gy);
+  by = (int)(t - (unsigned)bz * (unsigned)gy);
+}
+#endif
+
+int veex_env_int(const char* name, int dflt);   // cached getenv for tuning switches
 
 // launchers (host side; enqueue only, no sync, no allocation)
 int veex_launch_gather_gemm(const GGParams& p, hipStream_t st);

@@ -31,17 +31,31 @@ DECONVS = [
 ]
 
 
-def _time_launch(fn, iters=10, warm=2):
+def _time_launch(fn, iters=10, warm=2, rounds=3, warm_ms=30.0):
+    """Seconds per launch: HIP events on the launch stream; the chip is first kept busy for warm_ms
+    (an idle MI355X drops its clock and needs milliseconds of work to raise it again), then the
+    median of `rounds` timed groups of `iters` back-to-back launches is taken."""
+    import time
+    st = torch.cuda.current_stream()
     for _ in range(warm):
         fn()
-    st = torch.cuda.current_stream()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(st)
-    for _ in range(iters):
-        fn()
-    e1.record(st)
-    e1.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / iters     # seconds per launch
+    st.synchronize()
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < warm_ms:
+        for _ in range(4):
+            fn()
+        st.synchronize()
+    ts = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(iters):
+            fn()
+        e1.record(st)
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3 / iters)
+    ts.sort()
+    return ts[len(ts) // 2]     # seconds per launch
 
 
 def _rand(*shape):
@@ -136,6 +150,25 @@ def layer_table(B=512, iters=10):
     return rows
 
 
+_PMC_NOTE = ("HBM bytes per launch (read + write) from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+             "(tools/run_profiles.sh, batch 512; FETCH_SIZE doubled per the gfx950 correction), profiles/*_pmc_gemms.json")
+
+
+def _pmc_traffic(label):
+    """Per-launch HBM traffic of a GEMM from the newest committed PMC summary (counters cannot be
+    collected inside bench.py: they need rocprofv3 passes of their own)."""
+    import glob, json, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc_gemms.json")))
+    if not files:
+        return None
+    try:
+        e = json.load(open(files[-1]))[label]
+        return e["hbm_read_bytes"] + e["hbm_write_bytes"]
+    except (KeyError, ValueError, OSError):
+        return None
+
+
 def dominant_kernel_roofline(net, batch):
     """The MFMA launch with the largest share of the step (dec.deconv4 forward: the largest-FLOP
     layer), timed live with HIP events on the launch stream."""
@@ -145,9 +178,10 @@ def dominant_kernel_roofline(net, batch):
             continue
         t = _time_launch(fn, iters=20, warm=3)
         tf = 2.0 * macs / t / 1e12
+        traffic = _pmc_traffic("dec.deconv4.fwd")
         best = {"bound": "mfma", "kernel": "gather_gemm_kernel<128,64,mode1> (dec.deconv4 forward, Conv2DTranspose 128->64 k3 s1)",
                 "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
-                "traffic": None, "us_per_launch": t * 1e6, "algorithmic_flop_per_launch": 2.0 * macs}
+                "traffic": traffic, "traffic_source": _PMC_NOTE if traffic is not None else None, "us_per_launch": t * 1e6, "algorithmic_flop_per_launch": 2.0 * macs}
     return best
 
 
