@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=LOCAL_BATCH, help="local batch per GPU")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="arithmetic of the conv/deconv contractions: exact fp32 MFMA (parity path, default) or bf16 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -108,7 +110,7 @@ def main():
     from vae_eeg_xai_amd import roofline as rl
 
     B = args.batch
-    net = Net(LATENT, "vae")
+    net = Net(LATENT, "vae", compute=args.dtype)
     net.init_weights(seed=42)                      # same weights on every rank
     # weak scaling: every rank holds its own shard of the synthetic set (N_TRAIN / world maps)
     n_local = max(B, (N_TRAIN // world) // B * B)
@@ -148,13 +150,15 @@ def main():
         out = {
             "metric": "VAE train samples/sec", "value": sps, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": "configs[1]: models.py VAE train_step, 100k synthetic 40x40 topomaps, "
-                                   f"batch {B}/GPU, latent 28, Adam lr 1e-5, fp32 (exact-f32 MFMA)",
+                                   f"batch {B}/GPU, latent 28, Adam lr 1e-5, " +
+                                   ("fp32 (exact-f32 MFMA)" if args.dtype == "f32" else
+                                    "bf16 MFMA (fp32 accumulate / storage / master weights)"),
                        "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": loss},
             "train_tflops": sps * TRAIN_MACS * 2 / 1e12,
-            "frac_f32_mfma_peak": sps * TRAIN_MACS * 2 / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
+            "frac_mfma_peak": sps * TRAIN_MACS * 2 / 1e12 / ((PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else 2500.0) * world),
         }
         if not args.no_roofline:
             out["roofline"] = rl.dominant_kernel_roofline(net, B)

@@ -74,8 +74,15 @@ typedef struct VeexGemmDesc {
   int32_t epilogue, relu;
   int32_t e_channels;      /* epilogue 1: e_scale index = col & (e_channels-1) */
   int32_t nsplit;          /* epilogue 2 */
+  const void* weight_bf16; /* optional packed bf16 weights [tap][Cout][Cin] (veex_pack_weights_bf16): selects the
+                              bf16-MFMA kernel (fp32 accumulate) when Cin % 32 == 0 and N*Hout*Wout >= 4096 */
 } VeexGemmDesc;
 int veex_gather_gemm(const VeexGemmDesc* d, veexStream_t stream);
+/* bf16 copy of one layer's kernel for veex_gather_gemm: src fp32 [taps][rows][cols] ->
+ * dst bf16 [taps][rows][cols] (transpose=0) or [taps][cols][rows] (transpose=1).  Keras Conv2D kernels
+ * (kh,kw,Cin,Cout) need transpose=1 for the forward (mode 0) and 0 for the input gradient (mode 1);
+ * Conv2DTranspose kernels (kh,kw,Cout,Cin) the other way round. */
+int veex_pack_weights_bf16(const float* src, void* dst, int taps, int rows, int cols, int transpose, veexStream_t s);
 /* rows of the partials slab an epilogue-1 launch of this descriptor writes */
 int veex_gather_gemm_m_tiles(const VeexGemmDesc* d);
 
@@ -93,6 +100,8 @@ typedef struct VeexWgradDesc {
   int32_t N, Hb, Wb, Cb, Hs, Ws, Cs;
   int32_t kh, kw, stride, pad_begin;
   int32_t nsplit, rows_per_split;
+  int32_t bf16;            /* 1: round both operands to bf16 while staging, bf16 MFMA, fp32 accumulate
+                              (rows_per_split multiple of 32, Cb % 4 == 0, Cs % 4 == 0) */
 } VeexWgradDesc;
 int veex_wgrad_gemm(const VeexWgradDesc* d, veexStream_t stream);
 
@@ -159,6 +168,12 @@ int veex_net_tensor_info(const VeexNet* net, int i, char* name, int name_cap, lo
 long long veex_net_workspace_floats(const VeexNet* net, int batch);
 /* named workspace regions (activations "act.<layer>", gradients "dpre.<layer>", "z", "mulv", "eps", ...) for tests */
 long long veex_net_ws_offset(const VeexNet* net, int batch, const char* name, long long* nfloats);
+
+/* arithmetic of the conv / deconv contractions of a network: exact fp32 MFMA (default) or bf16 MFMA with
+ * fp32 accumulation, fp32 storage and fp32 master weights (north_star "fp32 reference plus bf16") */
+#define VEEX_COMPUTE_F32 0
+#define VEEX_COMPUTE_BF16 1
+int veex_net_set_compute(VeexNet* net, int compute);
 
 #define VEEX_F_PHILOX 1      /* generate epsilon on device (else read it from the eps argument) */
 #define VEEX_F_ZMEAN_DECODE 2 /* decode z_mean instead of the sampled z (not the reference's VAE.call) */

@@ -6,7 +6,7 @@ from vae_eeg_xai_amd._lib import lib
 from vae_eeg_xai_amd.roofline import _time_launch, _rand
 
 class GGParams(C.Structure):
-    _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("Out", C.c_void_p), ("a_scale", C.c_void_p), ("a_shift", C.c_void_p),
+    _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("Wbf", C.c_void_p), ("Out", C.c_void_p), ("a_scale", C.c_void_p), ("a_shift", C.c_void_p),
                 ("bias", C.c_void_p), ("aux", C.c_void_p), ("e_scale", C.c_void_p), ("partials", C.c_void_p),
                 ("Nb", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("Cin", C.c_int), ("Hout", C.c_int), ("Wout", C.c_int), ("Cout", C.c_int),
                 ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int), ("pb", C.c_int), ("mode", C.c_int),

@@ -31,6 +31,7 @@ class GemmDesc(C.Structure):
         ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad_begin", C.c_int32),
         ("mode", C.c_int32), ("affine_channels", C.c_int32), ("affine_spatial", C.c_int32),
         ("epilogue", C.c_int32), ("relu", C.c_int32), ("e_channels", C.c_int32), ("nsplit", C.c_int32),
+        ("weight_bf16", C.c_void_p),
     ]
 
 
@@ -45,7 +46,7 @@ class WgradDesc(C.Structure):
         ("N", C.c_int32), ("Hb", C.c_int32), ("Wb", C.c_int32), ("Cb", C.c_int32),
         ("Hs", C.c_int32), ("Ws", C.c_int32), ("Cs", C.c_int32),
         ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad_begin", C.c_int32),
-        ("nsplit", C.c_int32), ("rows_per_split", C.c_int32),
+        ("nsplit", C.c_int32), ("rows_per_split", C.c_int32), ("bf16", C.c_int32),
     ]
 
 
@@ -57,6 +58,8 @@ SIGNATURES = {
     "veex_abi_version": (_I, []),
     "veex_gather_gemm": (_I, [C.POINTER(GemmDesc), _P]),
     "veex_gather_gemm_m_tiles": (_I, [C.POINTER(GemmDesc)]),
+    "veex_pack_weights_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "veex_net_set_compute": (_I, [_P, _I]),
     "veex_wgrad_gemm": (_I, [C.POINTER(WgradDesc), _P]),
     "veex_conv1_fwd": (_I, [_P, _P, _P, _P, _I, _P]),
     "veex_conv1_wgrad_blocks": (_I, [_I]),
@@ -91,6 +94,7 @@ SIGNATURES = {
 F_PHILOX = 1
 F_ZMEAN_DECODE = 2
 VARIANT_VAE, VARIANT_AE = 0, 1
+COMPUTE_F32, COMPUTE_BF16 = 0, 1
 
 
 def _load():

@@ -1,0 +1,122 @@
+// Shared device helpers of the implicit-GEMM kernels (gather_gemm.hip, gather_gemm_bf16.hip).
+#ifndef VEEX_GG_COMMON_H
+#define VEEX_GG_COMMON_H
+#include "veex_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float4 ld4(const float* ptr, bool ok, int nvalid, bool vec) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) {
+    if (vec && nvalid >= 4) {
+      v = *reinterpret_cast<const float4*>(ptr);
+    } else {
+      if (nvalid > 0) v.x = ptr[0];
+      if (nvalid > 1) v.y = ptr[1];
+      if (nvalid > 2) v.z = ptr[2];
+      if (nvalid > 3) v.w = ptr[3];
+    }
+  }
+  return v;
+}
+
+// Shared epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
+                                            const int* s_off, float* As, int tile, int kz, int n0) {
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MT = WTM / 32, NT = WTN / 32;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lh = lane >> 5, l31 = lane & 31;
+  // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float cs1[NT], cs2[NT], cs3[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) { cs1[j] = 0.f; cs2[j] = 0.f; cs3[j] = 0.f; }
+
+  float* outp = p.Out;
+  if (p.epi == VEEX_EPI_RAW) outp += (long long)kz * p.slab_stride;
+
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + wn * WTN + j * 32 + l31;
+    const bool colok = col < p.Cout;
+    float bia = 0.f, esc = 1.f;
+    if (colok) {
+      if (p.epi == VEEX_EPI_FWD && p.bias != nullptr) bia = p.bias[col];
+      if (p.epi == VEEX_EPI_BWD && p.e_scale != nullptr) esc = p.e_scale[col & p.epi_cmask];
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int off = s_off[rl];
+        if (off < 0 || !colok) continue;
+        const long long addr = (long long)off * p.Cout + col;
+        float v = acc[i][j][r];
+        if (p.epi == VEEX_EPI_FWD) {
+          v += bia;
+          if (p.relu) v = fmaxf(v, 0.f);
+          outp[addr] = v;
+        } else if (p.epi == VEEX_EPI_BWD) {
+          const float a = p.aux[addr];
+          const bool on = (!p.relu) || (a > 0.f);
+          cs1[j] += v;
+          cs2[j] = fmaf(v, a, cs2[j]);
+          cs3[j] += on ? v : 0.f;
+          outp[addr] = on ? v * esc : 0.f;
+        } else {
+          outp[addr] = v;
+        }
+      }
+    }
+  }
+
+  if (p.epi == VEEX_EPI_BWD && p.partials != nullptr) {
+    // column sums: lane halves -> waves sharing the columns (wm) -> one row of the partial slab
+    float* s_red = As;   // [WM][BN][3]; safe: every wave passed the loop's last barrier
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      cs1[j] += __shfl_xor(cs1[j], 32);
+      cs2[j] += __shfl_xor(cs2[j], 32);
+      cs3[j] += __shfl_xor(cs3[j], 32);
+      if (lh == 0) {
+        const int cl = wn * WTN + j * 32 + l31;
+        s_red[(wm * BN + cl) * 3 + 0] = cs1[j];
+        s_red[(wm * BN + cl) * 3 + 1] = cs2[j];
+        s_red[(wm * BN + cl) * 3 + 2] = cs3[j];
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.Cout) {
+      float t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) {
+        t1 += s_red[(w * BN + tid) * 3 + 0];
+        t2 += s_red[(w * BN + tid) * 3 + 1];
+        t3 += s_red[(w * BN + tid) * 3 + 2];
+      }
+      float* pp = p.partials + (long long)tile * 3 * p.Cout + n0 + tid;
+      pp[0] = t1;
+      pp[p.Cout] = t2;
+      pp[2 * p.Cout] = t3;
+    }
+  }
+}
+
+typedef unsigned int v4u __attribute__((__vector_size__(16)));
+typedef float v4f __attribute__((__vector_size__(16)));
+#define VEEX_OOB 0xFFFFFF00u
+
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  const v4f f = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+  return make_float4(f[0], f[1], f[2], f[3]);
+}
+
+
+// launch-side helpers shared by the fp32 and bf16 engines
+int veex_launch_gather_gemm_bf16(GGParams& p, int mtiles, hipStream_t st);   // gather_gemm_bf16.hip
+
+#endif

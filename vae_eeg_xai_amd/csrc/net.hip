@@ -48,7 +48,7 @@ static inline int pow2_or_zero(int c) { return (c > 0 && (c & (c - 1)) == 0); }
 static int fill_gg(const VeexGemmDesc* d, GGParams& p) {
   if (d == nullptr) { veex_set_error("null descriptor"); return VEEX_EINVAL; }
   memset(&p, 0, sizeof(p));
-  p.A = d->in; p.W = d->weight; p.Out = d->out;
+  p.A = d->in; p.W = d->weight; p.Wbf = d->weight_bf16; p.Out = d->out;
   p.a_scale = d->in_scale; p.a_shift = d->in_shift;
   p.bias = d->bias; p.aux = d->aux; p.e_scale = d->e_scale; p.partials = d->partials;
   p.Nb = d->N; p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin;
@@ -111,7 +111,7 @@ static int fill_wg(const VeexWgradDesc* d, WGParams& p) {
   p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pb = d->pad_begin;
   p.R = p.Nb * p.Hs * p.Ws;
   p.M = p.kh * p.kw * p.Cb;
-  p.nsplit = d->nsplit; p.rows_per_split = d->rows_per_split;
+  p.nsplit = d->nsplit; p.rows_per_split = d->rows_per_split; p.bf16 = d->bf16;
   if (p.Big == nullptr || p.Small == nullptr || p.Out == nullptr) { veex_set_error("wgrad: null operand"); return VEEX_EINVAL; }
   return 0;
 }
@@ -146,6 +146,7 @@ struct ConvLayer {  // one Conv2D / Conv2DTranspose / Dense with optional BatchN
 
 struct VeexNet {
   int L, variant, H1;
+  int compute;                  // VEEX_COMPUTE_F32 / VEEX_COMPUTE_BF16
   long long n_params, n_state;
   int n_bn;                     // total BatchNorm channels
   long long gamma_off, beta_off;  // trainable buffer
@@ -166,7 +167,7 @@ extern "C" VeexNet* veex_net_create(int L, int variant) {
     return nullptr;
   }
   VeexNet* n = new VeexNet();
-  n->L = L; n->variant = variant;
+  n->L = L; n->variant = variant; n->compute = VEEX_COMPUTE_F32;
   n->H1 = (variant == VEEX_VARIANT_VAE) ? 100 : L;
   long long off = 0;
   int bnoff = 0;
@@ -257,6 +258,11 @@ extern "C" VeexNet* veex_net_create(int L, int variant) {
 }
 
 extern "C" void veex_net_destroy(VeexNet* n) { delete n; }
+extern "C" int veex_net_set_compute(VeexNet* n, int compute) {
+  if (n == nullptr || (compute != VEEX_COMPUTE_F32 && compute != VEEX_COMPUTE_BF16)) { veex_set_error("set_compute: bad arguments"); return VEEX_EINVAL; }
+  n->compute = compute;
+  return 0;
+}
 extern "C" long long veex_net_param_floats(const VeexNet* n) { return n ? n->n_params : -1; }
 extern "C" long long veex_net_state_floats(const VeexNet* n) { return n ? n->n_state : -1; }
 extern "C" int veex_net_num_tensors(const VeexNet* n) { return n ? (int)n->tensors.size() : -1; }
@@ -298,13 +304,14 @@ struct SplitPlan { int nsplit; int per; };  // per = rows_per_split (wgrad) or u
 static SplitPlan wgrad_split(const WGParams& pin) {
   int bm, bn;
   const int tiles = veex_wg_tiles(pin, &bm, &bn);
-  const int chunks = (pin.R + VEEX_BK - 1) / VEEX_BK;
+  const int bk = pin.bf16 ? 32 : VEEX_BK;   // reduction rows per K chunk of the kernel that will run
+  const int chunks = (pin.R + bk - 1) / bk;
   int ns = (768 + tiles - 1) / tiles;
   const int maxs = (chunks / 4 > 0) ? chunks / 4 : 1;
   if (ns > maxs) ns = maxs;
   if (ns < 1) ns = 1;
   const int cps = (chunks + ns - 1) / ns;
-  SplitPlan s; s.per = cps * VEEX_BK; s.nsplit = (pin.R + s.per - 1) / s.per;
+  SplitPlan s; s.per = cps * bk; s.nsplit = (pin.R + s.per - 1) / s.per;
   return s;
 }
 
@@ -327,6 +334,7 @@ struct Plan {
   long long d_conv[3], d_h, dmulv, dz, d_dd, g_dd, d_dc[5];
   long long slab, partials, losses_tmp;
   long long slab_n, partials_n;
+  long long wpack[7][2];   // bf16 weight copies (floats offset): layers conv2, conv3, deconv1..5; [0] as stored, [1] transposed
 };
 
 static long long act_floats(const ConvLayer& c, int B) { return (long long)B * c.Hout * c.Hout * c.Cout; }
@@ -335,12 +343,14 @@ static long long act_floats(const ConvLayer& c, int B) { return (long long)B * c
 static void wg_desc_deconv(const VeexNet* n, int i, int B, WGParams& p) {
   const ConvLayer& c = n->dc[i];
   memset(&p, 0, sizeof(p));
+  p.bf16 = (n->compute == VEEX_COMPUTE_BF16);
   p.Nb = B; p.Hb = c.Hout; p.Wb = c.Hout; p.Cb = c.Cout; p.Hs = c.Hin; p.Ws = c.Hin; p.Cs = c.Cin;
   p.kh = c.k; p.kw = c.k; p.stride = c.stride; p.pb = c.pb;
   p.R = B * c.Hin * c.Hin; p.M = c.k * c.k * c.Cout;
 }
-static void wg_desc_conv(const ConvLayer& c, int B, WGParams& p) {
+static void wg_desc_conv(const ConvLayer& c, int B, WGParams& p, int bf16 = 0) {
   memset(&p, 0, sizeof(p));
+  p.bf16 = bf16;
   p.Nb = B; p.Hb = c.Hin; p.Wb = c.Hin; p.Cb = c.Cin; p.Hs = c.Hout; p.Ws = c.Hout; p.Cs = c.Cout;
   p.kh = c.k; p.kw = c.k; p.stride = c.stride; p.pb = c.pb;
   p.R = B * c.Hout * c.Hout; p.M = c.k * c.k * c.Cin;
@@ -351,6 +361,9 @@ static long long gg_tiles_for(int B, int Hout, int Cout, int mode, int stride, i
   p.Nb = B; p.Hout = Hout; p.Wout = Hout; p.Cout = Cout; p.mode = mode; p.stride = stride; p.pb = pb;
   return veex_gg_m_tiles(p);
 }
+
+// the seven MFMA-bound layers that have a bf16 path: 0,1 = enc.conv2/3, 2..6 = dec.deconv1..5
+static const ConvLayer& big_layer(const VeexNet* n, int i) { return (i < 2) ? n->conv[i + 1] : n->dc[i - 2]; }
 
 static void make_plan(const VeexNet* n, int B, Plan& P) {
   Ws& w = P.ws;
@@ -388,7 +401,7 @@ static void make_plan(const VeexNet* n, int B, Plan& P) {
   auto upd = [](long long& m, long long v) { if (v > m) m = v; };
   WGParams wp;
   for (int i = 0; i < 5; ++i) { wg_desc_deconv(n, i, B, wp); upd(slab, (long long)wgrad_split(wp).nsplit * wp.M * wp.Cs); }
-  for (int i = 1; i < 3; ++i) { wg_desc_conv(n->conv[i], B, wp); upd(slab, (long long)wgrad_split(wp).nsplit * wp.M * wp.Cs); }
+  for (int i = 1; i < 3; ++i) { wg_desc_conv(n->conv[i], B, wp, n->compute == VEEX_COMPUTE_BF16); upd(slab, (long long)wgrad_split(wp).nsplit * wp.M * wp.Cs); }
   wg_desc_conv(n->dense, B, wp); upd(slab, (long long)wgrad_split(wp).nsplit * wp.M * wp.Cs);
   wg_desc_conv(n->ddense, B, wp); upd(slab, (long long)wgrad_split(wp).nsplit * wp.M * wp.Cs);
   if (n->variant == VEEX_VARIANT_VAE) {
@@ -416,6 +429,12 @@ static void make_plan(const VeexNet* n, int B, Plan& P) {
   P.slab_n = slab; P.partials_n = part;
   P.slab = w.add("scratch.slab", slab);
   P.partials = w.add("scratch.partials", part);
+  for (int i = 0; i < 7; ++i) {
+    const ConvLayer& l = big_layer(n, i);
+    const long long halfs = (long long)l.k * l.k * l.Cin * l.Cout;
+    P.wpack[i][0] = w.add(std::string("wpack.") + l.name + ".a", (halfs + 1) / 2);
+    P.wpack[i][1] = w.add(std::string("wpack.") + l.name + ".t", (halfs + 1) / 2);
+  }
 }
 
 extern "C" long long veex_net_workspace_floats(const VeexNet* n, int B) {
@@ -456,7 +475,28 @@ static int check_common(const VeexNet* n, const void* params, const void* state,
   return 0;
 }
 
+// bf16 copies of the seven big kernels from the fp32 master weights (once per call: the weights change every step)
+static int run_pack_weights(Ctx& c) {
+  if (c.n->compute != VEEX_COMPUTE_BF16) return 0;
+  for (int i = 0; i < 7; ++i) {
+    const ConvLayer& l = big_layer(c.n, i);
+    // Conv2D kernels are (kh,kw,Cin,Cout), Conv2DTranspose kernels (kh,kw,Cout,Cin)
+    const int rows = (i < 2) ? l.Cin : l.Cout, cols = (i < 2) ? l.Cout : l.Cin;
+    TRY(veex_pack_weights_bf16(c.P + l.w, c.ws + c.plan.wpack[i][0], l.k * l.k, rows, cols, 0, c.st));
+    TRY(veex_pack_weights_bf16(c.P + l.w, c.ws + c.plan.wpack[i][1], l.k * l.k, rows, cols, 1, c.st));
+  }
+  return 0;
+}
+// packed weights [tap][Cout_gemm][Cin_gemm] for the forward (fwd=1) or input-gradient GEMM of big layer i
+static const void* packed_w(const Ctx& c, int i, int fwd) {
+  if (c.n->compute != VEEX_COMPUTE_BF16) return nullptr;
+  const int conv = (i < 2);
+  const int which = (conv == (fwd != 0)) ? 1 : 0;   // conv fwd / deconv dgrad: transposed copy
+  return c.ws + c.plan.wpack[i][which];
+}
+
 static int run_bn_prepare(Ctx& c) {
+  TRY(run_pack_weights(c));
   const VeexNet* n = c.n;
   return veex_bn_prepare(c.P + n->gamma_off, c.P + n->beta_off, c.S, c.S + n->n_bn, c.ws + c.plan.bn_scale,
                          c.ws + c.plan.bn_shift, c.ws + c.plan.bn_rstd, n->n_bn, BN_EPS, c.st);
@@ -464,9 +504,9 @@ static int run_bn_prepare(Ctx& c) {
 
 // forward GEMM layer: in (with producer BN) -> out = relu?(conv + bias)
 static int fwd_gemm(Ctx& c, const ConvLayer& l, int mode, const float* in, int in_bn, int in_bnC, int aff_spatial,
-                    float* out, int relu) {
+                    float* out, int relu, const void* wp = nullptr) {
   GGParams p; memset(&p, 0, sizeof(p));
-  p.A = in; p.W = c.P + l.w; p.Out = out; p.bias = c.P + l.b;
+  p.A = in; p.W = c.P + l.w; p.Wbf = wp; p.Out = out; p.bias = c.P + l.b;
   if (in_bn >= 0) { p.a_scale = c.scale(in_bn); p.a_shift = c.shift(in_bn); p.aff_mask = in_bnC - 1; p.aff_spatial = aff_spatial; }
   p.Nb = c.B; p.Hin = l.Hin; p.Win = l.Hin; p.Cin = l.Cin; p.Hout = l.Hout; p.Wout = l.Hout; p.Cout = l.Cout;
   p.kh = l.k; p.kw = l.k; p.stride = l.stride; p.pb = l.pb; p.mode = mode;
@@ -479,8 +519,8 @@ static int encoder_forward(Ctx& c, const float* x) {
   const Plan& P = c.plan;
   float* ws = c.ws;
   TRY(veex_conv1_fwd(x, c.P + n->conv[0].w, c.P + n->conv[0].b, ws + P.act_conv[0], c.B, c.st));
-  TRY(fwd_gemm(c, n->conv[1], 0, ws + P.act_conv[0], n->conv[0].bn, 64, 0, ws + P.act_conv[1], 1));
-  TRY(fwd_gemm(c, n->conv[2], 0, ws + P.act_conv[1], n->conv[1].bn, 128, 0, ws + P.act_conv[2], 1));
+  TRY(fwd_gemm(c, n->conv[1], 0, ws + P.act_conv[0], n->conv[0].bn, 64, 0, ws + P.act_conv[1], 1, packed_w(c, 0, 1)));
+  TRY(fwd_gemm(c, n->conv[2], 0, ws + P.act_conv[1], n->conv[1].bn, 128, 0, ws + P.act_conv[2], 1, packed_w(c, 1, 1)));
   {  // Dense(6400 -> H1, relu) as a 5x5 VALID conv, split-K over taps/channels
     const ConvLayer& l = n->dense;
     GGParams p; memset(&p, 0, sizeof(p));
@@ -516,7 +556,7 @@ static int decoder_trunk(Ctx& c, const float* z) {
   const float* in = ws + P.act_dd;
   int in_bn = n->ddense.bn, in_bnC = 4096, spatial = 1;
   for (int i = 0; i < 5; ++i) {
-    TRY(fwd_gemm(c, n->dc[i], 1, in, in_bn, in_bnC, spatial, ws + P.act_dc[i], 1));
+    TRY(fwd_gemm(c, n->dc[i], 1, in, in_bn, in_bnC, spatial, ws + P.act_dc[i], 1, packed_w(c, i + 2, 1)));
     in = ws + P.act_dc[i]; in_bn = n->dc[i].bn; in_bnC = n->dc[i].Cout; spatial = 0;
   }
   return 0;
@@ -581,13 +621,13 @@ static int encoder_backward(Ctx& c, const float* x, float* G, int want_param_gra
   for (int i = 2; i >= 1; --i) {
     const ConvLayer& l = n->conv[i];
     if (want_param_grads) {
-      WGParams w; wg_desc_conv(l, c.B, w);
+      WGParams w; wg_desc_conv(l, c.B, w, n->compute == VEEX_COMPUTE_BF16);
       w.Big = ws + P.act_conv[i - 1]; w.Small = ws + P.d_conv[i];
       w.b_scale = c.scale(n->conv[i - 1].bn); w.b_shift = c.shift(n->conv[i - 1].bn); w.b_aff_mask = n->conv[i - 1].Cout - 1;
       TRY(run_wgrad(c, w, G + l.w));
     }
     GGParams p; memset(&p, 0, sizeof(p));
-    p.A = ws + P.d_conv[i]; p.W = c.P + l.w;
+    p.A = ws + P.d_conv[i]; p.W = c.P + l.w; p.Wbf = packed_w(c, i - 1, 0);
     p.Nb = c.B; p.Hin = p.Win = l.Hout; p.Cin = l.Cout; p.Hout = p.Wout = l.Hin; p.Cout = l.Cin;
     p.kh = p.kw = 3; p.stride = 2; p.pb = l.pb; p.mode = 1;
     TRY(dgrad_bwd(c, p, n->conv[i - 1], ws + P.act_conv[i - 1], ws + P.d_conv[i - 1], G, want_param_grads));
@@ -727,7 +767,7 @@ extern "C" int veex_net_train_fwd_bwd(const VeexNet* n, const float* params, con
       TRY(run_wgrad(c, w, G + l.w));
     }
     GGParams p; memset(&p, 0, sizeof(p));
-    p.A = ws + P.d_dc[i]; p.W = c.P + l.w;
+    p.A = ws + P.d_dc[i]; p.W = c.P + l.w; p.Wbf = packed_w(c, i + 2, 0);
     p.Nb = B; p.Hin = p.Win = l.Hout; p.Cin = l.Cout; p.Hout = p.Wout = l.Hin; p.Cout = l.Cin;
     p.kh = p.kw = l.k; p.stride = l.stride; p.pb = l.pb; p.mode = 0;
     if (i > 0) {

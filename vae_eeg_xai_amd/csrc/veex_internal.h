@@ -20,6 +20,7 @@ enum { VEEX_EPI_FWD = 0, VEEX_EPI_BWD = 1, VEEX_EPI_RAW = 2 };
 struct GGParams {
   const float* A;        // gathered operand, NHWC [Nb][Hin][Win][Cin]
   const float* W;
+  const void* Wbf;        // optional packed bf16 weights [tap][Cout][Cin]: run the bf16-MFMA kernel
   float* Out;            // NHWC [Nb][Hout][Wout][Cout]; RAW: slab base [nsplit][same]
   const float* a_scale;  // optional per-channel affine applied to in-bounds A loads (producer's BN)
   const float* a_shift;
@@ -60,6 +61,7 @@ struct WGParams {
   int rows_per_split;    // multiple of VEEX_BK
   int M;                 // kh*kw*Cb
   int nsplit;
+  int bf16;              // 1: bf16 MFMA (operands rounded while staging)
   int gx, gy, gz;        // logical grid (m tiles, n tiles, row splits), filled by the launcher
   int remap;
 };
@@ -89,6 +91,9 @@ int veex_launch_wgrad(const WGParams& p, hipStream_t st);
 int veex_gg_m_tiles(GGParams& p);   // fills phase tables; returns total m tiles for the chosen config
 int veex_gg_bm(int Cout, long long M);
 int veex_wg_tiles(const WGParams& p, int* bm, int* bn);
+int veex_wgrad_bf16_ok(const WGParams& p);                       // wgrad_gemm_bf16.hip
+int veex_launch_wgrad_bf16(const WGParams& p, hipStream_t st);
+extern "C" int veex_pack_weights_bf16(const float* src, void* dst, int taps, int rows, int cols, int transpose, hipStream_t st);
 
 void veex_set_error(const char* fmt, ...);
 

@@ -434,6 +434,7 @@ int veex_launch_wgrad(const WGParams& p, hipStream_t st) {
     return -1;
   }
   if (p.kh * p.kw > 1 && (p.Cb & 3) != 0) { veex_set_error("wgrad: multi-tap layers need Cb %% 4 == 0"); return -1; }
+  if (veex_wgrad_bf16_ok(p)) return veex_launch_wgrad_bf16(p, st);
   int bm, bn;
   veex_wg_tiles(p, &bm, &bn);
   const long long big_bytes = (long long)p.Nb * p.Hb * p.Wb * p.Cb * 4, small_bytes = (long long)p.R * p.Cs * 4;

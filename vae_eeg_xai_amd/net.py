@@ -39,7 +39,7 @@ def _as_device_f32(a, device) -> torch.Tensor:
 class Net:
     """One VAE (variant 'vae', models.py) or plain autoencoder ('ae', models_standard.py)."""
 
-    def __init__(self, latent_dim: int, variant: str = "vae", device: Optional[str] = None):
+    def __init__(self, latent_dim: int, variant: str = "vae", device: Optional[str] = None, compute: str = "f32"):
         if not torch.cuda.is_available():
             raise _lib.VeexError("no GPU visible: vae_eeg_xai_amd has no CPU path")
         self.device = torch.device(device or f"cuda:{torch.cuda.current_device()}")
@@ -48,6 +48,9 @@ class Net:
         self._h = lib.veex_net_create(self.latent_dim, _lib.VARIANT_VAE if variant == "vae" else _lib.VARIANT_AE)
         if not self._h:
             raise _lib.VeexError(lib.veex_last_error().decode())
+        self.compute = "f32"
+        self._ws: Dict[int, torch.Tensor] = {}
+        self.set_compute(compute)
         self.n_params = lib.veex_net_param_floats(self._h)
         self.n_state = lib.veex_net_state_floats(self._h)
         self.specs: List[TensorSpec] = []
@@ -70,7 +73,6 @@ class Net:
             self.adam_step_count = torch.zeros(1, dtype=torch.int32, device=self.device)
             self.adam_alpha = torch.zeros(1, dtype=torch.float32, device=self.device)
             self.metrics = torch.zeros(4, dtype=torch.float32, device=self.device)
-        self._ws: Dict[int, torch.Tensor] = {}
         self.philox_seed = 42
         self.samples_seen = 0
         self.reset_bn_state()
@@ -80,6 +82,18 @@ class Net:
         if h:
             lib.veex_net_destroy(h)
             self._h = None
+
+    def set_compute(self, compute: str):
+        """Arithmetic of the seven MFMA-bound conv / deconv layers (forward, input and weight
+        gradients): "f32" = exact fp32 MFMA (parity path), "bf16" = bf16 MFMA with fp32 accumulation,
+        fp32 activations in HBM and fp32 master weights.  Layers too small for a 128-row tile
+        (N*Hout*Wout < 4096) stay on the fp32 kernels."""
+        if compute not in ("f32", "bf16"):
+            raise ValueError("compute must be 'f32' or 'bf16'")
+        check(lib.veex_net_set_compute(self._h, _lib.COMPUTE_BF16 if compute == "bf16" else _lib.COMPUTE_F32),
+              "net_set_compute")
+        self.compute = compute
+        self._ws.clear()            # the workspace plan (split-K slabs) depends on the kernel family
 
     # ---------------- parameters ----------------
     def view(self, spec: TensorSpec, buf: Optional[torch.Tensor] = None) -> torch.Tensor:

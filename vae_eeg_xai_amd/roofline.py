@@ -16,6 +16,7 @@ from ._lib import lib, check, GemmDesc, WgradDesc
 
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+PEAK_BF16_MFMA_TFLOPS = 2500.0
 
 # (name, Cin, Cout, k, stride, pad_begin, Hin, Hout, exact forward MACs per sample [SURVEY 8a])
 CONVS = [
@@ -62,15 +63,25 @@ def _rand(*shape):
     return torch.rand(*shape, device="cuda", dtype=torch.float32) - 0.5
 
 
-def gemm_cases(B):
+def _pack(W, transpose):
+    """bf16 copy [tap][Cout_gemm][Cin_gemm] of a (k,k,rows,cols) kernel (veex_pack_weights_bf16)."""
+    k, _, rows, cols = W.shape
+    dst = torch.empty(W.numel(), dtype=torch.bfloat16, device="cuda")
+    check(lib.veex_pack_weights_bf16(_lib.ptr(W), _lib.ptr(dst), k * k, rows, cols, transpose, _lib.current_stream()), "pack")
+    return dst
+
+
+def gemm_cases(B, bf16=False):
     """Yield (label, macs, launch_fn) for every MFMA launch of one train step at batch B."""
     stream = _lib.current_stream
     keep = []
 
     def gg(label, macs, mode, A, W, out, N, Hin, Cin, Hout, Cout, k, stride, pb, aff=None, spatial=0, epi=0,
-           aux=None, esc=None):
+           aux=None, esc=None, wbf=None):
         d = GemmDesc()
         d.inp, d.weight, d.out = A.data_ptr(), W.data_ptr(), out.data_ptr()
+        if wbf is not None:
+            keep.append(wbf); d.weight_bf16 = wbf.data_ptr()
         if aff is not None:
             d.in_scale, d.in_shift, d.affine_channels, d.affine_spatial = aff[0].data_ptr(), aff[1].data_ptr(), aff[0].numel(), spatial
         if epi == 0:
@@ -102,10 +113,12 @@ def gemm_cases(B):
         R = N * Hs * Hs
         M = k * k * Cb
         tiles = ((M + 127) // 128) * ((Cs + 127) // 128 if Cs > 64 else 1)
-        chunks = (R + 15) // 16
+        bk = 32 if bf16 else 16
+        d.bf16 = 1 if bf16 else 0
+        chunks = (R + bk - 1) // bk
         ns = max(1, min((768 + tiles - 1) // tiles, max(chunks // 4, 1)))
         cps = (chunks + ns - 1) // ns
-        d.rows_per_split = cps * 16
+        d.rows_per_split = cps * bk
         d.nsplit = (R + d.rows_per_split - 1) // d.rows_per_split
         out = torch.empty(d.nsplit * M * Cs, device="cuda")
         d.out = out.data_ptr()
@@ -118,9 +131,10 @@ def gemm_cases(B):
         W = _rand(k, k, cin, cout) * 0.1
         aff = (torch.rand(cin, device="cuda") + 0.5, _rand(cin))
         dy = _rand(B, hout, hout, cout); dx = torch.empty_like(x)
-        cases.append(gg(f"{name}.fwd", macs * B, 0, x, W, y, B, hin, cin, hout, cout, k, s, pb, aff=aff))
+        wt, wa = (_pack(W, 1), _pack(W, 0)) if bf16 else (None, None)
+        cases.append(gg(f"{name}.fwd", macs * B, 0, x, W, y, B, hin, cin, hout, cout, k, s, pb, aff=aff, wbf=wt))
         cases.append(gg(f"{name}.dgrad", macs * B, 1, dy, W, dx, B, hout, cout, hin, cin, k, s, pb, epi=1, aux=x,
-                        esc=aff[0]))
+                        esc=aff[0], wbf=wa))
         cases.append(wg(f"{name}.wgrad", macs * B, x, dy, B, hin, cin, hout, cout, k, s, pb, aff_big=aff))
     for name, cin, cout, k, s, pb, hin, hout, macs in DECONVS:
         x = _rand(B, hin, hin, cin); y = torch.empty(B, hout, hout, cout, device="cuda")
@@ -129,24 +143,26 @@ def gemm_cases(B):
         nch = hin * hin * cin if spatial else cin
         aff = (torch.rand(nch, device="cuda") + 0.5, _rand(nch))
         dy = _rand(B, hout, hout, cout); dx = torch.empty_like(x)
-        cases.append(gg(f"{name}.fwd", macs * B, 1, x, W, y, B, hin, cin, hout, cout, k, s, pb, aff=aff, spatial=spatial))
+        wt, wa = (_pack(W, 1), _pack(W, 0)) if bf16 else (None, None)
+        cases.append(gg(f"{name}.fwd", macs * B, 1, x, W, y, B, hin, cin, hout, cout, k, s, pb, aff=aff, spatial=spatial, wbf=wa))
         if spatial:
-            cases.append(gg(f"{name}.dgrad", macs * B, 0, dy, W, dx, B, hout, cout, hin, cin, k, s, pb))
+            cases.append(gg(f"{name}.dgrad", macs * B, 0, dy, W, dx, B, hout, cout, hin, cin, k, s, pb, wbf=wt))
         else:
             cases.append(gg(f"{name}.dgrad", macs * B, 0, dy, W, dx, B, hout, cout, hin, cin, k, s, pb, epi=1, aux=x,
-                            esc=aff[0]))
+                            esc=aff[0], wbf=wt))
         if not spatial:
             cases.append(wg(f"{name}.wgrad", macs * B, dy, x, B, hout, cout, hin, cin, k, s, pb, aff_small=aff))
     gemm_cases._keep = keep
     return cases
 
 
-def layer_table(B=512, iters=10):
+def layer_table(B=512, iters=10, bf16=False):
     rows = []
-    for label, macs, fn in gemm_cases(B):
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    for label, macs, fn in gemm_cases(B, bf16):
         t = _time_launch(fn, iters)
         tf = 2.0 * macs / t / 1e12
-        rows.append({"kernel": label, "us": t * 1e6, "tflops": tf, "frac": tf / PEAK_F32_MFMA_TFLOPS})
+        rows.append({"kernel": label, "us": t * 1e6, "tflops": tf, "frac": tf / peak})
     return rows
 
 
@@ -173,14 +189,19 @@ def dominant_kernel_roofline(net, batch):
     """The MFMA launch with the largest share of the step (dec.deconv4 forward: the largest-FLOP
     layer), timed live with HIP events on the launch stream."""
     best = None
-    for label, macs, fn in gemm_cases(batch):
+    bf16 = getattr(net, "compute", "f32") == "bf16"
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    for label, macs, fn in gemm_cases(batch, bf16):
         if label != "dec.deconv4.fwd":
             continue
         t = _time_launch(fn, iters=20, warm=3)
         tf = 2.0 * macs / t / 1e12
         traffic = _pmc_traffic("dec.deconv4.fwd")
-        best = {"bound": "mfma", "kernel": "gather_gemm_kernel<128,64,mode1> (dec.deconv4 forward, Conv2DTranspose 128->64 k3 s1)",
-                "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
+        if bf16:
+            traffic = None   # PMC passes of the bf16 kernels: profiles/*_pmc_gemms_bf16.json when collected
+        best = {"bound": "mfma", "kernel": ("gather_gemm_bf16_kernel" if bf16 else "gather_gemm_kernel") +
+                "<128,64,mode1> (dec.deconv4 forward, Conv2DTranspose 128->64 k3 s1)",
+                "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                 "traffic": traffic, "traffic_source": _PMC_NOTE if traffic is not None else None, "us_per_launch": t * 1e6, "algorithmic_flop_per_launch": 2.0 * macs}
     return best
 
@@ -188,8 +209,9 @@ def dominant_kernel_roofline(net, batch):
 if __name__ == "__main__":
     import sys
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    bf = len(sys.argv) > 2 and sys.argv[2] == "bf16"
     tot = 0.0
-    for r in layer_table(B):
+    for r in layer_table(B, bf16=bf):
         tot += r["us"]
-        print(f"{r['kernel']:22s} {r['us']:8.1f} us  {r['tflops']:6.1f} TF  {100 * r['frac']:5.1f}% of f32 MFMA peak")
+        print(f"{r['kernel']:22s} {r['us']:8.1f} us  {r['tflops']:6.1f} TF  {100 * r['frac']:5.1f}% of {'bf16' if bf else 'f32'} MFMA peak")
     print(f"sum {tot:.1f} us")
