@@ -79,6 +79,49 @@ def cpu_baseline(seconds_budget=15.0):
             "sample": f"{i} train steps of batch 64 (config[0] shape, 1k synthetic maps) in {dt:.1f}s, torch-CPU fp32 restatement"}
 
 
+ATTR_BATCH = 4096          # config[3]: attribution batches of 4096 maps
+ATTR_MACS_FWD = 14_177_584   # encoder forward without the unused log-variance head
+ATTR_MACS_BWD = 14_177_584   # encoder input-gradient chain incl. conv1
+
+
+def attribution_bench(net, x_all, world, iters=8, warmup=2):
+    """config[3]: saliency maps d z_mean[:, j] / d x back to the 40x40 electrode grid, inputs sharded
+    over ranks (replicas only, no collective).  One map = one (sample, latent unit) pair.  Returns
+    whole-job maps/s for k=1 (analysis.py:725 picks the top-1 unit) and for all 28 units."""
+    import torch
+    import torch.distributed as dist
+    B = min(ATTR_BATCH, x_all.shape[0])
+    nb = x_all.shape[0] // B
+    out = {}
+    for label, units in (("top1", [3]), ("all28", list(range(LATENT)))):
+        def step(i):
+            net.attribute(x_all[(i % nb) * B:(i % nb + 1) * B], units, grad_x_input=True)
+        for i in range(warmup):
+            step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(iters):
+            step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        maps = iters * B * len(units) * world
+        flop = 2.0 * (ATTR_MACS_FWD * iters * B + ATTR_MACS_BWD * iters * B * len(units)) * world
+        out[label] = {"maps_per_s": maps / dt, "ms_per_batch": 1e3 * dt / iters, "tflops": flop / dt / 1e12}
+    return {"metric": "attribution maps/sec (gradient x input, latent unit -> 40x40 grid)", "unit": "maps/s",
+            "value": out["top1"]["maps_per_s"], "batch_per_gpu": B, "units": 1, "top1": out["top1"], "all28": out["all28"],
+            "sharding": "inputs split across ranks, replicas only"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +132,7 @@ def main():
                     help="arithmetic of the conv/deconv contractions: exact fp32 MFMA (parity path, default) or bf16 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-attribution", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -144,6 +188,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = float(net.grads[net.n_params].item()) / world
+    attr = None if args.no_attribution else attribution_bench(net, x_all, world)
 
     if rank == 0:
         sps = args.steps * B * world / dt
@@ -160,6 +205,8 @@ def main():
             "train_tflops": sps * TRAIN_MACS * 2 / 1e12,
             "frac_mfma_peak": sps * TRAIN_MACS * 2 / 1e12 / ((PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else 2500.0) * world),
         }
+        if attr is not None:
+            out["attribution"] = attr
         if not args.no_roofline:
             out["roofline"] = rl.dominant_kernel_roofline(net, B)
         if world == 1 and not args.no_cpu_baseline:

@@ -12,7 +12,7 @@ if "--only" in sys.argv:
 names = [a.split("=")[0] for a in args]
 vals = [a.split("=")[1].split(",") for a in args]
 combos = list(itertools.product(*vals))
-cases = rl.gemm_cases(512)
+cases = rl.gemm_cases(512, bf16=("--bf16" in sys.argv))
 print("kernel".ljust(22) + "".join(("/".join(c)).rjust(12) for c in combos), " (us; vars: " + ",".join(names) + ")")
 tot = [0.0] * len(combos)
 for label, macs, fn in cases:

@@ -525,9 +525,19 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-int veex_gg_bm(int Cout, long long M) {
-  (void)Cout;
-  return (M >= 4096) ? 128 : 64;
+// Rows per tile.  Measured at batch 512 (tools/ab_env.py VEEX_BM=64,128): the fp32 engine is faster with
+// 64x64 tiles on every layer (-3..-45 %: 8 resident blocks per CU overlap each other's prologues,
+// barriers and epilogues; the f32 MFMA is slow enough that operand re-use is not the limit); the bf16
+// engine keeps 128-row tiles for forward launches (operand re-use matters at 16x the MFMA rate) and
+// takes 64x64 for the heavier BatchNorm/ReLU-backward epilogue and for launches of < 256 blocks.
+int veex_gg_bm(const GGParams& p) {
+  const long long M = (long long)p.Nb * p.Hout * p.Wout;
+  if (M < 4096) return 64;
+  const int force = veex_env_int("VEEX_BM", 0);
+  if (force == 64 || force == 128) return force;
+  if (p.Wbf == nullptr || p.Cin % 32 != 0) return 64;
+  const long long blocks = ((M + 127) / 128) * ((p.Cout > 64) ? (p.Cout + 127) / 128 : 1);
+  return (p.epi == VEEX_EPI_BWD || blocks < 256) ? 64 : 128;
 }
 
 static int gg_bn(int Cout, int bm) {
@@ -535,9 +545,10 @@ static int gg_bn(int Cout, int bm) {
   return (Cout > 64) ? 128 : 64;
 }
 
-int veex_gg_m_tiles(GGParams& p) {
+int veex_gg_m_tiles(GGParams& p) { return veex_gg_m_tiles_bm(p, veex_gg_bm(p)); }
+
+int veex_gg_m_tiles_bm(GGParams& p, int bm) {
   const long long Mtot = (long long)p.Nb * p.Hout * p.Wout;
-  const int bm = veex_gg_bm(p.Cout, Mtot);
   if (p.mode == 1 && p.stride == 2) {
     p.nphase = 4;
     for (int par = 0; par < 2; ++par) {
@@ -649,7 +660,7 @@ int veex_launch_gather_gemm(const GGParams& pin, hipStream_t st) {
     veex_set_error("gather_gemm: split-K needs RAW epilogue and a single phase"); return -1;
   }
   if (p.nsplit == 1) p.chunks_per_split = 1 << 30;
-  const int bm = veex_gg_bm(p.Cout, Mtot);
+  const int bm = veex_gg_bm(p);
   const int bn = gg_bn(p.Cout, bm);
   // fast path: 16-byte buffer loads everywhere, 32-bit byte offsets, tap-validity bit mask
   const long long a_bytes = (long long)p.Nb * p.Hin * p.Win * p.Cin * 4;
@@ -657,7 +668,7 @@ int veex_launch_gather_gemm(const GGParams& pin, hipStream_t st) {
   const bool vec_ok = (p.Cin % 4 == 0) && (p.mode == 1 || p.Cout % 4 == 0);
   const bool fast = vec_ok && a_bytes < 0x7FFF0000LL && w_bytes < 0x7FFF0000LL && p.kh * p.kw <= 32 &&
                     (p.a_scale == nullptr || !p.aff_spatial || (p.aff_mask + 1) == p.Hin * p.Win * p.Cin);
-  if (p.Wbf != nullptr && fast && bm == 128 && p.Cin % 32 == 0) return veex_launch_gather_gemm_bf16(p, mtiles, st);
+  if (p.Wbf != nullptr && fast && Mtot >= 4096 && p.Cin % 32 == 0) return veex_launch_gather_gemm_bf16(p, mtiles, st);
   if (bm == 128 && bn == 128 && fast) return gg_launch_cfg<128, 128>(p, mtiles, true, st);
   if (bm == 128 && bn == 64 && fast) return gg_launch_cfg<128, 64>(p, mtiles, true, st);
   if (bm == 64 && fast) return gg_launch_cfg<64, 64>(p, mtiles, true, st);

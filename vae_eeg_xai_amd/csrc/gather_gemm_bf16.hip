@@ -281,10 +281,8 @@ static int ggb_launch(const GGParams& p, dim3 grid, hipStream_t st) {
 // p: validated by veex_launch_gather_gemm, phase tables filled (veex_gg_m_tiles), p.Wbf != nullptr
 int veex_launch_gather_gemm_bf16(GGParams& p, int mtiles, hipStream_t st) {
   if (p.Cin % 32 != 0) { veex_set_error("gather_gemm(bf16): Cin %% 32 == 0 required (got %d)", p.Cin); return -1; }
-  const long long Mtot = (long long)p.Nb * p.Hout * p.Wout;
-  const int bm = veex_gg_bm(p.Cout, Mtot);
-  if (bm != 128) { veex_set_error("gather_gemm(bf16): needs M >= 4096"); return -1; }
-  const int bn = (p.Cout > 64) ? 128 : 64;
+  const int bm = veex_gg_bm(p);
+  const int bn = (bm == 128 && p.Cout > 64) ? 128 : 64;
   const int ntiles = (p.Cout + bn - 1) / bn;
   if (p.nsplit > 1) {
     const int nchunks = p.kh * p.kw * (p.Cin / 32);
@@ -295,6 +293,7 @@ int veex_launch_gather_gemm_bf16(GGParams& p, int mtiles, hipStream_t st) {
   p.tap_inner = veex_env_int("VEEX_TAPIN", 1);
   p.gx = ntiles; p.gy = mtiles; p.gz = p.nsplit;
   dim3 grid((unsigned)ntiles * mtiles * p.nsplit, 1, 1);
+  if (bm == 64) return (p.mode == 1) ? ggb_launch<64, 64, true>(p, grid, st) : ggb_launch<64, 64, false>(p, grid, st);
   if (bn == 128) return (p.mode == 1) ? ggb_launch<128, 128, true>(p, grid, st) : ggb_launch<128, 128, false>(p, grid, st);
   return (p.mode == 1) ? ggb_launch<128, 64, true>(p, grid, st) : ggb_launch<128, 64, false>(p, grid, st);
 }

@@ -359,7 +359,7 @@ static void wg_desc_conv(const ConvLayer& c, int B, WGParams& p, int bf16 = 0) {
 static long long gg_tiles_for(int B, int Hout, int Cout, int mode, int stride, int pb) {
   GGParams p; memset(&p, 0, sizeof(p));
   p.Nb = B; p.Hout = Hout; p.Wout = Hout; p.Cout = Cout; p.mode = mode; p.stride = stride; p.pb = pb;
-  return veex_gg_m_tiles(p);
+  return veex_gg_m_tiles_bm(p, 64);   // 64-row tiles: an upper bound whatever tile the launcher picks
 }
 
 // the seven MFMA-bound layers that have a bf16 path: 0,1 = enc.conv2/3, 2..6 = dec.deconv1..5
@@ -534,6 +534,7 @@ static int encoder_forward(Ctx& c, const float* x) {
     p.nsplit = gg_split(mt, l.Cout, chunks);
     p.chunks_per_split = (chunks + p.nsplit - 1) / p.nsplit;
     p.slab_stride = (long long)c.B * l.Cout;
+    if ((long long)p.nsplit * p.slab_stride > P.slab_n) { veex_set_error("internal: slab scratch too small (enc.dense)"); return VEEX_ENOMEM; }
     TRY(veex_launch_gather_gemm(p, c.st));
     TRY(veex_slab_sum(ws + P.slab, p.nsplit, p.slab_stride, p.slab_stride, ws + P.act_h, c.P + l.b, l.Cout, 1, c.st));
   }
@@ -796,6 +797,7 @@ extern "C" int veex_net_train_fwd_bwd(const VeexNet* n, const float* params, con
     p.nsplit = gg_split(mt, L, chunks);
     p.chunks_per_split = (chunks + p.nsplit - 1) / p.nsplit;
     p.slab_stride = (long long)B * L;
+    if ((long long)p.nsplit * p.slab_stride > P.slab_n) { veex_set_error("internal: slab scratch too small (dz)"); return VEEX_ENOMEM; }
     TRY(veex_launch_gather_gemm(p, st));
     TRY(veex_slab_sum(ws + P.slab, p.nsplit, p.slab_stride, p.slab_stride, ws + P.dz, nullptr, 1, 0, st));
   }

@@ -89,7 +89,8 @@ int veex_env_int(const char* name, int dflt);   // cached getenv for tuning swit
 int veex_launch_gather_gemm(const GGParams& p, hipStream_t st);
 int veex_launch_wgrad(const WGParams& p, hipStream_t st);
 int veex_gg_m_tiles(GGParams& p);   // fills phase tables; returns total m tiles for the chosen config
-int veex_gg_bm(int Cout, long long M);
+int veex_gg_m_tiles_bm(GGParams& p, int bm);   // same for a given tile height (64: upper bound for sizing)
+int veex_gg_bm(const GGParams& p);
 int veex_wg_tiles(const WGParams& p, int* bm, int* bn);
 int veex_wgrad_bf16_ok(const WGParams& p);                       // wgrad_gemm_bf16.hip
 int veex_launch_wgrad_bf16(const WGParams& p, hipStream_t st);

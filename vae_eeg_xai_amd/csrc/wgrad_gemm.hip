@@ -399,6 +399,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGParams p) {
 int veex_wg_tiles(const WGParams& p, int* bm, int* bn) {
   *bn = (p.Cs > 64) ? 128 : 64;
   *bm = (p.M > 64) ? 128 : 64;
+  const int t = veex_env_int("VEEX_WG_TILE", 0);   // tuning: 1 = 64x64, 2 = 128x64, 3 = 64x128
+  if (t == 1) { *bm = 64; *bn = 64; }
+  else if (t == 2) { *bn = 64; }
+  else if (t == 3) { *bm = 64; }
   const int mt = (p.M + *bm - 1) / *bm, nt = (p.Cs + *bn - 1) / *bn;
   return mt * nt;
 }

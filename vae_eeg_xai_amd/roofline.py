@@ -95,7 +95,10 @@ def gemm_cases(B, bf16=False):
         d.kh = d.kw = k
         d.stride, d.pad_begin, d.mode, d.epilogue, d.nsplit = stride, pb, mode, epi, 1
         if epi == 1:
-            mt = lib.veex_gather_gemm_m_tiles(C.byref(d))
+            # sized for the smallest tile (64 rows, 4 phases) so that tile-size switches flipped by
+            # environment variables between launches can never overrun it
+            mt = (N * Hout * Hout + 63) // 64 + 4
+            assert lib.veex_gather_gemm_m_tiles(C.byref(d)) <= mt
             part = torch.empty(mt * 3 * Cout, device="cuda"); keep.append(part); d.partials = part.data_ptr()
         keep.extend([A, W, out, d])
         return label, macs, (lambda d=d: check(lib.veex_gather_gemm(C.byref(d), stream()), label))
@@ -200,7 +203,7 @@ def dominant_kernel_roofline(net, batch):
         if bf16:
             traffic = None   # PMC passes of the bf16 kernels: profiles/*_pmc_gemms_bf16.json when collected
         best = {"bound": "mfma", "kernel": ("gather_gemm_bf16_kernel" if bf16 else "gather_gemm_kernel") +
-                "<128,64,mode1> (dec.deconv4 forward, Conv2DTranspose 128->64 k3 s1)",
+                " mode 1 (dec.deconv4 forward, Conv2DTranspose 128->64 k3 s1)",
                 "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                 "traffic": traffic, "traffic_source": _PMC_NOTE if traffic is not None else None, "us_per_launch": t * 1e6, "algorithmic_flop_per_launch": 2.0 * macs}
     return best
