@@ -710,35 +710,26 @@ extern "C" int veexi_debug_mfma_peak(float* out, int blocks, int iters, hipStrea
   case D_: hipLaunchKernelGGL((gather_gemm_kernel<BM_, BN_, 2, 2, M1_, AFF_, 16, D_>), grid, dim3(256), lds, st, p); break;
 
 // Timing-only variants for profiling (outputs are wrong by construction). dbg bits: 1 = no global loads in
-// the K loop, 2 = no MFMA, 4 = no barrier, 8 = no LDS store.
+// the K loop, 2 = no MFMA, 4 = no barrier, 8 = no LDS store, 16 = no epilogue.  64x64 tiles: mode 1 with a
+// per-channel affine (a Conv2DTranspose forward) or mode 0 without (its input gradient).
 extern "C" int veexi_debug_gather_gemm(const GGParams* pin, int dbg, hipStream_t st) {
   GGParams p = *pin;
-  const int mtiles = veex_gg_m_tiles(p);
+  const int mtiles = veex_gg_m_tiles_bm(p, 64);
   p.nsplit = 1; p.chunks_per_split = 1 << 30;
-  if (p.mode == 1 && p.Cout <= 64) {
-    p.gx = 1; p.gy = mtiles; p.gz = 1; p.remap = veex_env_int("VEEX_XCD", 1); p.tap_inner = veex_env_int("VEEX_TAPIN", 1);
-    dim3 grid(mtiles, 1, 1);
-    constexpr size_t lds = gg_lds_bytes<128, 64, true, 16>();
+  p.gx = (p.Cout + 63) / 64; p.gy = mtiles; p.gz = 1;
+  p.remap = (p.nphase == 1); p.tap_inner = veex_env_int("VEEX_TAPIN", 1);
+  dim3 grid(mtiles * p.gx, 1, 1);
+  constexpr size_t lds = gg_lds_bytes<64, 64, true, 16>();
+  if (p.mode == 1) {
     switch (dbg) {
-      DBG_CASE(128, 64, true, 1, 0) DBG_CASE(128, 64, true, 1, 1) DBG_CASE(128, 64, true, 1, 2)
-      DBG_CASE(128, 64, true, 1, 5) DBG_CASE(128, 64, true, 1, 9) DBG_CASE(128, 64, true, 1, 13)
-      DBG_CASE(128, 64, true, 1, 16) DBG_CASE(128, 64, true, 1, 32) DBG_CASE(128, 64, true, 1, 48) DBG_CASE(128, 64, true, 1, 29)
+      DBG_CASE(64, 64, true, 1, 0) DBG_CASE(64, 64, true, 1, 1) DBG_CASE(64, 64, true, 1, 16)
+      DBG_CASE(64, 64, true, 1, 13) DBG_CASE(64, 64, true, 1, 29) DBG_CASE(64, 64, true, 1, 17)
       default: return -1;
     }
   } else {
-    p.gx = (p.Cout + 127) / 128; p.gy = mtiles; p.gz = 1; p.remap = veex_env_int("VEEX_XCD", 1); p.tap_inner = veex_env_int("VEEX_TAPIN", 1);
-    dim3 grid(mtiles * p.gx, 1, 1);
-    constexpr size_t lds = gg_lds_bytes<128, 128, false, 16>();
-    static bool done = false;
-    if (!done) {
-      gg_set_lds(gather_gemm_kernel<128, 128, 2, 2, false, 0, 16, 0>, lds); gg_set_lds(gather_gemm_kernel<128, 128, 2, 2, false, 0, 16, 1>, lds);
-      gg_set_lds(gather_gemm_kernel<128, 128, 2, 2, false, 0, 16, 2>, lds); gg_set_lds(gather_gemm_kernel<128, 128, 2, 2, false, 0, 16, 5>, lds);
-      gg_set_lds(gather_gemm_kernel<128, 128, 2, 2, false, 0, 16, 9>, lds); gg_set_lds(gather_gemm_kernel<128, 128, 2, 2, false, 0, 16, 13>, lds);
-      done = true;
-    }
     switch (dbg) {
-      DBG_CASE(128, 128, false, 0, 0) DBG_CASE(128, 128, false, 0, 1) DBG_CASE(128, 128, false, 0, 2)
-      DBG_CASE(128, 128, false, 0, 5) DBG_CASE(128, 128, false, 0, 9) DBG_CASE(128, 128, false, 0, 13)
+      DBG_CASE(64, 64, false, 0, 0) DBG_CASE(64, 64, false, 0, 1) DBG_CASE(64, 64, false, 0, 16)
+      DBG_CASE(64, 64, false, 0, 13) DBG_CASE(64, 64, false, 0, 29) DBG_CASE(64, 64, false, 0, 17)
       default: return -1;
     }
   }

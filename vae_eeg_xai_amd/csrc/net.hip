@@ -306,7 +306,8 @@ static SplitPlan wgrad_split(const WGParams& pin) {
   const int tiles = veex_wg_tiles(pin, &bm, &bn);
   const int bk = pin.bf16 ? 32 : VEEX_BK;   // reduction rows per K chunk of the kernel that will run
   const int chunks = (pin.R + bk - 1) / bk;
-  int ns = (768 + tiles - 1) / tiles;
+  const int target = veex_env_int("VEEX_WG_BLOCKS", 768);   // blocks per launch the row split aims at
+  int ns = (target + tiles - 1) / tiles;
   const int maxs = (chunks / 4 > 0) ? chunks / 4 : 1;
   if (ns > maxs) ns = maxs;
   if (ns < 1) ns = 1;
