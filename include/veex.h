@@ -150,6 +150,19 @@ int veex_slab_sum(const float* slab, int nsplit, long long stride, long long n, 
 int veex_adam(float* p, const float* g, float* m, float* v, long long n, int* step, float* alpha, double lr,
               double gscale, double b1, double b2, double eps, veexStream_t s);
 
+/* Either side of the path.  Bit-identical to the reference's NumPy float32 expressions.
+ * veex_minmax: global min / max of x[n] -> minmax[2] (partials: veex_minmax_partial_blocks(n)*2 floats);
+ * veex_normalize: (x - min) / (max - min), train.py:99-100;  veex_denormalize: x*(max-min)+min,
+ * signal_reconstruction.py:92-95;  veex_electrode_readout: out[b][e] = maps[b][pix[e]] (optionally
+ * denormalized, minmax nullable), the pixel-per-electrode gather of indian_functions.py:146-160
+ * (pix[e] = row*width + col; the host validates 0 <= pix[e] < map_elems). */
+int veex_minmax_partial_blocks(long long n);
+int veex_minmax(const float* x, long long n, float* partials, float* minmax, veexStream_t s);
+int veex_normalize(const float* x, const float* minmax, float* out, long long n, veexStream_t s);
+int veex_denormalize(const float* x, const float* minmax, float* out, long long n, veexStream_t s);
+int veex_electrode_readout(const float* maps, const int* pix, const float* minmax, float* out, int batch,
+                           int map_elems, int n_electrodes, veexStream_t s);
+
 /* ------------------------------------------------------------------------------------------
  * Network level: the whole Encoder / Decoder / VAE.train_step graph as one enqueue.
  * ---------------------------------------------------------------------------------------- */

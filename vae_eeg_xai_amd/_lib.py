@@ -75,6 +75,11 @@ SIGNATURES = {
     "veex_colsum_finalize": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "veex_slab_sum": (_I, [_P, _I, _L, _L, _P, _P, _I, _I, _P]),
     "veex_adam": (_I, [_P, _P, _P, _P, _L, _P, _P, _D, _D, _D, _D, _D, _P]),
+    "veex_minmax_partial_blocks": (_I, [_L]),
+    "veex_minmax": (_I, [_P, _L, _P, _P, _P]),
+    "veex_normalize": (_I, [_P, _P, _P, _L, _P]),
+    "veex_denormalize": (_I, [_P, _P, _P, _L, _P]),
+    "veex_electrode_readout": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "veex_net_create": (_P, [_I, _I]),
     "veex_net_destroy": (None, [_P]),
     "veex_net_param_floats": (_L, [_P]),

@@ -1,0 +1,157 @@
+// The steps either side of the hot path, HBM-bound, fp32:
+//   normalize(x)   = (x - min(x)) / (max(x) - min(x)) over the WHOLE array      reference train.py:99-100
+//   denormalize    = x_norm * (max - min) + min                                  reference signal_reconstruction.py:92-95
+//   electrode read-out: one pixel per electrode gathered from every 40x40 map    reference indian_functions.py:146-160
+// The arithmetic is the reference's fp32 expression op for op (subtract, IEEE divide; multiply,
+// add -- no FMA contraction), so results are bit-identical to NumPy float32.
+#include "veex_internal.h"
+#include <float.h>
+
+#pragma clang fp contract(off)
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// pass 1: per-block (min, max) partials [blocks][2]; min/max are exact whatever the order
+__global__ __launch_bounds__(256) void minmax_partial_kernel(const float* __restrict__ x, long long n, float* __restrict__ part) {
+  float lo = FLT_MAX, hi = -FLT_MAX;
+  const long long n4 = n >> 2;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = x4[i];
+    lo = fminf(fminf(lo, v.x), fminf(v.y, fminf(v.z, v.w)));
+    hi = fmaxf(fmaxf(hi, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {
+    const float v = x[(n4 << 2) + threadIdx.x];
+    lo = fminf(lo, v); hi = fmaxf(hi, v);
+  }
+  lo = wave_min(lo); hi = wave_max(hi);
+  __shared__ float s[8];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s[w] = lo; s[4 + w] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = fminf(fminf(s[0], s[1]), fminf(s[2], s[3]));
+    part[2 * blockIdx.x + 1] = fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7]));
+  }
+}
+
+// pass 2: one block folds the partials into minmax[2]
+__global__ __launch_bounds__(256) void minmax_final_kernel(const float* __restrict__ part, int blocks, float* __restrict__ minmax) {
+  float lo = FLT_MAX, hi = -FLT_MAX;
+  for (int i = threadIdx.x; i < blocks; i += 256) { lo = fminf(lo, part[2 * i]); hi = fmaxf(hi, part[2 * i + 1]); }
+  lo = wave_min(lo); hi = wave_max(hi);
+  __shared__ float s[8];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s[w] = lo; s[4 + w] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    minmax[0] = fminf(fminf(s[0], s[1]), fminf(s[2], s[3]));
+    minmax[1] = fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7]));
+  }
+}
+
+// out = (x - lo) / (hi - lo)   (train.py:100; a constant array gives 0/0 = NaN like NumPy)
+__global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ x, const float* __restrict__ minmax,
+                                                        float* __restrict__ out, long long n) {
+  const float lo = minmax[0], range = minmax[1] - minmax[0];
+  const long long n4 = n >> 2;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  float4* o4 = reinterpret_cast<float4*>(out);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 v = x4[i];
+    v.x = (v.x - lo) / range; v.y = (v.y - lo) / range; v.z = (v.z - lo) / range; v.w = (v.w - lo) / range;
+    o4[i] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {
+    const long long i = (n4 << 2) + threadIdx.x;
+    out[i] = (x[i] - lo) / range;
+  }
+}
+
+// out[b][e] = maps[b][pix[e]] * (hi - lo) + lo   (denormalize fused into the electrode gather;
+// minmax == nullptr: plain gather).  One wave per map: 64 lanes cover up to 64 electrodes per pass.
+__global__ __launch_bounds__(256) void electrode_readout_kernel(const float* __restrict__ maps, const int* __restrict__ pix,
+                                                                const float* __restrict__ minmax, float* __restrict__ out,
+                                                                int batch, int map_elems, int n_el) {
+  const int lane = threadIdx.x & 63;
+  float lo = 0.f, range = 1.f;
+  const bool den = minmax != nullptr;
+  if (den) { lo = minmax[0]; range = minmax[1] - minmax[0]; }
+  for (int b = blockIdx.x * 4 + (threadIdx.x >> 6); b < batch; b += gridDim.x * 4) {
+    const float* m = maps + (long long)b * map_elems;
+    for (int e = lane; e < n_el; e += 64) {
+      float v = m[pix[e]];
+      if (den) { v = v * range; v = v + lo; }
+      out[(long long)b * n_el + e] = v;
+    }
+  }
+}
+
+// out = x * (hi - lo) + lo  (signal_reconstruction.py:94), whole maps
+__global__ __launch_bounds__(256) void denormalize_kernel(const float* __restrict__ x, const float* __restrict__ minmax,
+                                                          float* __restrict__ out, long long n) {
+  const float lo = minmax[0], range = minmax[1] - minmax[0];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float v = x[i] * range;
+    out[i] = v + lo;
+  }
+}
+
+static inline int blocks_for(long long work, long long per_block, int cap) {
+  long long b = (work + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+extern "C" {
+
+int veex_minmax_partial_blocks(long long n) { return blocks_for(n, 256 * 16, 2048); }
+
+int veex_minmax(const float* x, long long n, float* partials, float* minmax, hipStream_t st) {
+  if (x == nullptr || partials == nullptr || minmax == nullptr || n < 1) { veex_set_error("minmax: bad arguments"); return -1; }
+  if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) { veex_set_error("minmax: x must be 16-byte aligned"); return -1; }
+  const int blocks = veex_minmax_partial_blocks(n);
+  hipLaunchKernelGGL(minmax_partial_kernel, dim3(blocks), dim3(256), 0, st, x, n, partials);
+  hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(256), 0, st, partials, blocks, minmax);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+int veex_normalize(const float* x, const float* minmax, float* out, long long n, hipStream_t st) {
+  if (x == nullptr || out == nullptr || minmax == nullptr || n < 1) { veex_set_error("normalize: bad arguments"); return -1; }
+  if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) != 0) { veex_set_error("normalize: buffers must be 16-byte aligned"); return -1; }
+  hipLaunchKernelGGL(normalize_kernel, dim3(blocks_for(n, 256 * 16, 4096)), dim3(256), 0, st, x, minmax, out, n);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+int veex_denormalize(const float* x, const float* minmax, float* out, long long n, hipStream_t st) {
+  if (x == nullptr || out == nullptr || minmax == nullptr || n < 1) { veex_set_error("denormalize: bad arguments"); return -1; }
+  hipLaunchKernelGGL(denormalize_kernel, dim3(blocks_for(n, 256 * 8, 4096)), dim3(256), 0, st, x, minmax, out, n);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+int veex_electrode_readout(const float* maps, const int* pix, const float* minmax, float* out, int batch, int map_elems,
+                           int n_electrodes, hipStream_t st) {
+  if (maps == nullptr || pix == nullptr || out == nullptr || batch < 1 || map_elems < 1 || n_electrodes < 1) {
+    veex_set_error("electrode_readout: bad arguments"); return -1;
+  }
+  hipLaunchKernelGGL(electrode_readout_kernel, dim3(blocks_for(batch, 4, 4096)), dim3(256), 0, st, maps, pix, minmax, out,
+                     batch, map_elems, n_electrodes);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"
