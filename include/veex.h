@@ -188,6 +188,12 @@ long long veex_net_ws_offset(const VeexNet* net, int batch, const char* name, lo
 #define VEEX_COMPUTE_BF16 1
 int veex_net_set_compute(VeexNet* net, int compute);
 
+/* Optional second stream (caller-owned, same device): veex_net_train_fwd_bwd then runs every weight-gradient GEMM
+ * and its slab reduction there, concurrently with the input-gradient chain on the main stream, and makes the main
+ * stream wait for it before returning (fork/join with events the net creates on first use; capturable).
+ * NULL (default) = everything on the one stream passed to the call. */
+int veex_net_set_side_stream(VeexNet* net, veexStream_t side);
+
 #define VEEX_F_PHILOX 1      /* generate epsilon on device (else read it from the eps argument) */
 #define VEEX_F_ZMEAN_DECODE 2 /* decode z_mean instead of the sampled z (not the reference's VAE.call) */
 

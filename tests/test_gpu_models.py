@@ -91,3 +91,33 @@ def test_attribute_api():
     vae = VAE(Encoder(28), Decoder())
     maps = vae.attribute(x, [1, 2], batch_size=4)
     assert maps.shape == (2, 10, 40, 40) and np.isfinite(maps).all() and np.abs(maps).max() > 0
+
+
+def test_keras_weight_list_interchange_and_masked_decode(tmp_path):
+    """weights in keras get_weights() order travel through .npz (and, opt-in, the
+    reference's pickle, train.py:287-289), trailing metric scalars are ignored; masked decode = decode of z
+    with one unit set to its np.median (analysis.py:574-581)."""
+    import pickle
+    import numpy as np
+    from oracle import vae_oracle as vo
+    from vae_eeg_xai_amd.models import Encoder, Decoder, VAE
+    L = 8
+    a = VAE(Encoder(L), Decoder()); b = VAE(Encoder(L), Decoder()); c = VAE(Encoder(L), Decoder())
+    ws = a.get_weights()
+    names = [n for n, *_ in vo.param_spec(L, "vae")]
+    assert len(ws) == len(names) == 62
+    np.savez(tmp_path / "w.npz", *ws)
+    b.load_keras_weight_list(tmp_path / "w.npz")
+    with open(tmp_path / "w.pickle", "wb") as fp:
+        pickle.dump(ws + [np.float32(3.0), np.float32(7.0)], fp)       # + metric total / count
+    with pytest.raises(ValueError):
+        c.load_keras_weight_list(tmp_path / "w.pickle")
+    c.load_keras_weight_list(tmp_path / "w.pickle", allow_pickle=True)
+    for m in (b, c):
+        for u, v in zip(ws, m.get_weights()):
+            assert np.array_equal(u, v)
+    z = np.random.default_rng(0).standard_normal((11, L)).astype(np.float32)
+    zm = z.copy(); zm[:, 3] = np.median(z[:, 3])
+    assert np.array_equal(np.asarray(a.decode_masked(z, 3)), np.asarray(a.decoder(zm)))
+    zv = z.copy(); zv[:, 0] = 0.25
+    assert np.array_equal(np.asarray(a.decode_masked(z, 0, value=0.25)), np.asarray(a.decoder(zv)))

@@ -250,3 +250,37 @@ def test_full_size_properties_batch512():
         net.adam_step(1e-3)
     last = net.train_fwd_bwd(x, eps)[0].item()
     assert last < first
+
+
+def test_side_stream_overlap_is_bit_identical_and_graph_capturable():
+    """The weight-gradient GEMMs on the second stream (fork/join inside veex_net_train_fwd_bwd) must not
+    change a single bit, and the fork/join must survive HIP-graph capture."""
+    import torch
+    from vae_eeg_xai_amd.net import Net
+    L, B = 28, 96
+    p, x, eps = _case("vae", L, B, seed=9)
+    res = []
+    for overlap in (False, True):
+        net = Net(L, "vae", overlap=overlap)
+        net.set_weights_dict(p)
+        for _ in range(3):
+            net.train_fwd_bwd(x, eps)
+        torch.cuda.synchronize()
+        res.append(net.grads.clone())
+    assert torch.equal(res[0], res[1])
+    # capture one step (side stream forks and joins inside the capture), replay, compare
+    net = Net(L, "vae", overlap=True)
+    net.set_weights_dict(p)
+    xs = torch.from_numpy(x).cuda(); es = torch.from_numpy(eps).cuda()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        net.train_fwd_bwd(xs, es)          # warm-up: function attributes, events, workspace
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            net.train_fwd_bwd(xs, es, accumulate_metrics=False)
+    net.grads.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(net.grads, res[0])

@@ -60,6 +60,7 @@ SIGNATURES = {
     "veex_gather_gemm_m_tiles": (_I, [C.POINTER(GemmDesc)]),
     "veex_pack_weights_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "veex_net_set_compute": (_I, [_P, _I]),
+    "veex_net_set_side_stream": (_I, [_P, _P]),
     "veex_wgrad_gemm": (_I, [C.POINTER(WgradDesc), _P]),
     "veex_conv1_fwd": (_I, [_P, _P, _P, _P, _I, _P]),
     "veex_conv1_wgrad_blocks": (_I, [_I]),

@@ -337,7 +337,44 @@ class VAE:
         return self._net.get_weights()
 
     def set_weights(self, weights):
+        """keras Model.set_weights order.  Also accepts the list a real Keras run pickled
+        with ``vae.get_weights()`` (reference train.py:287-289): Keras may append the metric trackers'
+        scalar ``total`` / ``count`` variables after the layer weights; trailing scalars are dropped."""
+        weights = [np.asarray(w) for w in weights]
+        n = len(self._net.specs)
+        if len(weights) > n and all(w.size == 1 for w in weights[n:]):
+            weights = weights[:n]
         self._net.set_weights(weights)
+
+    def load_keras_weight_list(self, path, allow_pickle=False):
+        """Weights exported from the reference: a ``.npz`` with arrays ``arr_0 .. arr_k`` in
+        ``get_weights()`` order (np.savez(path, *vae.get_weights())), or -- only with
+        ``allow_pickle=True``, because unpickling executes code -- the pickle of that list which the
+        reference itself writes (train.py:287-289)."""
+        path = str(path)
+        if path.endswith(".npz"):
+            with np.load(path, allow_pickle=False) as f:
+                ws = [f[f"arr_{i}"] for i in range(len(f.files))]
+        elif allow_pickle:
+            import pickle
+            with open(path, "rb") as fp:
+                ws = pickle.load(fp)
+        else:
+            raise ValueError("a pickled weight list is only read with allow_pickle=True (it executes code); "
+                             "re-export it with np.savez(path, *weights)")
+        self.set_weights(ws)
+
+    def decode_masked(self, z, unit, value="median"):
+        """Latent masking of the reference's analysis (analysis.py:574-581): overwrite latent unit
+        ``unit`` of every row of ``z`` with its median over the set (np.median semantics) or with
+        ``value``, then decode.  Everything stays on the device."""
+        zt = _as_device_f32(z, self._net.device).clone()
+        j = int(unit)
+        if not 0 <= j < zt.shape[1]:
+            raise IndexError(f"latent unit {j} out of range")
+        v = torch.quantile(zt[:, j], 0.5) if (isinstance(value, str) and value == "median") else float(value)
+        zt[:, j] = v
+        return DeviceArray(self._net.decode(zt))
 
     def save_weights(self, filepath, save_format=None, **kwargs):
         d = self._net.get_weights_dict()

@@ -39,7 +39,8 @@ def _as_device_f32(a, device) -> torch.Tensor:
 class Net:
     """One VAE (variant 'vae', models.py) or plain autoencoder ('ae', models_standard.py)."""
 
-    def __init__(self, latent_dim: int, variant: str = "vae", device: Optional[str] = None, compute: str = "f32"):
+    def __init__(self, latent_dim: int, variant: str = "vae", device: Optional[str] = None, compute: str = "f32",
+                 overlap: bool = True):
         if not torch.cuda.is_available():
             raise _lib.VeexError("no GPU visible: vae_eeg_xai_amd has no CPU path")
         self.device = torch.device(device or f"cuda:{torch.cuda.current_device()}")
@@ -51,6 +52,8 @@ class Net:
         self.compute = "f32"
         self._ws: Dict[int, torch.Tensor] = {}
         self.set_compute(compute)
+        self._side_stream = None
+        self.set_overlap(overlap)
         self.n_params = lib.veex_net_param_floats(self._h)
         self.n_state = lib.veex_net_state_floats(self._h)
         self.specs: List[TensorSpec] = []
@@ -94,6 +97,16 @@ class Net:
               "net_set_compute")
         self.compute = compute
         self._ws.clear()            # the workspace plan (split-K slabs) depends on the kernel family
+
+    def set_overlap(self, on: bool):
+        """Run the weight-gradient GEMMs of the backward pass on a second HIP stream, concurrently
+        with the input-gradient chain (joined before train_fwd_bwd returns)."""
+        if on and self._side_stream is None:
+            with torch.cuda.device(self.device):
+                self._side_stream = torch.cuda.Stream(device=self.device)
+        s = self._side_stream.cuda_stream if on else None
+        check(lib.veex_net_set_side_stream(self._h, C.c_void_p(s) if s is not None else None), "net_set_side_stream")
+        self.overlap = bool(on)
 
     # ---------------- parameters ----------------
     def view(self, spec: TensorSpec, buf: Optional[torch.Tensor] = None) -> torch.Tensor:
