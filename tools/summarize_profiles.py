@@ -14,7 +14,7 @@ shutil.copy(f"{src}/layer_table.txt", f"{dst}/{R}_layer_table.txt")
 ks = newest(f"{src}/trace/*/*kernel_stats.csv")
 shutil.copy(ks, f"{dst}/{R}_kernel_stats.csv")
 with open(f"{dst}/{R}_kernel_stats.txt", "w") as f:
-    f.write("rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline\n")
+    f.write("rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-attribution\n")
     for r in csv.DictReader(open(ks)):
         f.write(f"{r['Name'][:100]:100s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs']) / 1e3:9.1f} pct={float(r['Percentage']):6.2f}\n")
 

@@ -92,38 +92,58 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
 }
 
 // dx[n][iy][ix] = sum_{ky,kx,co} dpre1[n][(iy-ky)/2][(ix-kx)/2][co] * W1[ky][kx][co]  (attribution only)
-// 16 lanes per input pixel, 4 channels per lane.  mul (nullable) = x for gradient*input.
+// One block per sample, dpre1 streamed exactly once:
+//   phase 1: per conv1 output pixel the 9 tap dot products over 64 channels (4 lanes x 16 channels,
+//            weights broadcast from LDS, 2-step shuffle reduce) -> T[400][9] in LDS
+//   phase 2: per input pixel gather its <= 4 contributions from T, times mul (gradient*input), store.
 __global__ __launch_bounds__(256) void conv1_dgrad_kernel(const float* __restrict__ dpre, const float* __restrict__ W,
-                                                          const float* __restrict__ mul, float* __restrict__ dx,
-                                                          int npix) {
-  const int cq = threadIdx.x & 15, pg = threadIdx.x >> 4;
-  float4 w[9];
+                                                          const float* __restrict__ mul, float* __restrict__ dx) {
+  __shared__ __attribute__((aligned(16))) float sW[9 * NCH];
+  __shared__ float sT[C1H * C1H * 9];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < 9 * NCH; i += 256) sW[i] = W[i];
+  __syncthreads();
+  const int l4 = tid & 3, g = tid >> 2;
+  const float* src = dpre + (long long)n * (C1H * C1H * NCH) + 16 * l4;
+  for (int pix = g; pix < C1H * C1H; pix += 64) {
+    float4 v[4];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const float4*>(W + t * NCH + 4 * cq);
-  const int iters = (npix + gridDim.x * 16 - 1) / (gridDim.x * 16);
-  for (int it = 0; it < iters; ++it) {
-    const int pix = (it * gridDim.x + blockIdx.x) * 16 + pg;
+    for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const float4*>(src + (long long)pix * NCH + 4 * c);
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float a = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 w = *reinterpret_cast<const float4*>(sW + t * NCH + 16 * l4 + 4 * c);
+        a = fmaf(v[c].x, w.x, a); a = fmaf(v[c].y, w.y, a); a = fmaf(v[c].z, w.z, a); a = fmaf(v[c].w, w.w, a);
+      }
+      a += __shfl_xor(a, 1);
+      a += __shfl_xor(a, 2);
+      acc[t] = a;
+    }
+    if (l4 == 0) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) sT[pix * 9 + t] = acc[t];
+    }
+  }
+  __syncthreads();
+  for (int o = tid; o < IMG * IMG; o += 256) {
+    const int iy = o / IMG, ix = o - iy * IMG;
     float s = 0.f;
-    if (pix < npix) {
-      const int n = pix / (IMG * IMG), rem = pix - n * (IMG * IMG);
-      const int iy = rem / IMG, ix = rem - iy * IMG;
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int ty = iy - ky;
-        if (ty < 0 || (ty & 1) || (ty >> 1) >= C1H) continue;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int ty = iy - ky;
+      if (ty < 0 || (ty & 1) || (ty >> 1) >= C1H) continue;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int tx = ix - kx;
-          if (tx < 0 || (tx & 1) || (tx >> 1) >= C1H) continue;
-          const float4 g = *reinterpret_cast<const float4*>(
-              dpre + ((long long)(n * C1H + (ty >> 1)) * C1H + (tx >> 1)) * NCH + 4 * cq);
-          const float4 ww = w[ky * 3 + kx];
-          s = fmaf(g.x, ww.x, s); s = fmaf(g.y, ww.y, s); s = fmaf(g.z, ww.z, s); s = fmaf(g.w, ww.w, s);
-        }
+      for (int kx = 0; kx < 3; ++kx) {
+        const int tx = ix - kx;
+        if (tx < 0 || (tx & 1) || (tx >> 1) >= C1H) continue;
+        s += sT[((ty >> 1) * C1H + (tx >> 1)) * 9 + ky * 3 + kx];
       }
     }
-    s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
-    if (cq == 0 && pix < npix) dx[pix] = (mul != nullptr) ? s * mul[pix] : s;
+    const long long oi = (long long)n * (IMG * IMG) + o;
+    dx[oi] = (mul != nullptr) ? s * mul[oi] : s;
   }
 }
 
@@ -565,8 +585,8 @@ int veex_conv1_wgrad(const float* x, const float* dpre, float* slab, int B, hipS
 }
 
 int veex_conv1_dgrad(const float* dpre, const float* W, const float* mul, float* dx, int B, hipStream_t st) {
-  const int npix = B * IMG * IMG;
-  hipLaunchKernelGGL(conv1_dgrad_kernel, dim3(grid_for(npix, 16, 8192)), dim3(256), 0, st, dpre, W, mul, dx, npix);
+  if (dpre == nullptr || W == nullptr || dx == nullptr || B < 1) { veex_set_error("conv1_dgrad: bad arguments"); return -1; }
+  hipLaunchKernelGGL(conv1_dgrad_kernel, dim3(B), dim3(256), 0, st, dpre, W, mul, dx);
   VEEX_CHECK_LAUNCH();
   return 0;
 }
