@@ -74,6 +74,13 @@ typedef struct VeexGemmDesc {
   int32_t epilogue, relu;
   int32_t e_channels;      /* epilogue 1: e_scale index = col & (e_channels-1) */
   int32_t nsplit;          /* epilogue 2 */
+  const void* in_bf16;     /* optional bf16 consumer copy of `in` with its BatchNorm already applied (an out_bf16 of
+                              the producer): read instead of in / in_scale / in_shift by the bf16 kernel */
+  void* out_bf16;          /* optional: also write bf16(out_scale[c]*out + out_shift[c]) (epilogue 0; this layer's
+                              BatchNorm, nullable = plain rounding) or bf16(out) (epilogue 1) */
+  const float* out_scale; const float* out_shift;
+  int32_t out_channels;    /* power of two; out_scale index = col & (out_channels-1) */
+  int32_t reserved_;
   const void* weight_bf16; /* optional packed bf16 weights [tap][Cout][Cin] (veex_pack_weights_bf16): selects the
                               bf16-MFMA kernel (fp32 accumulate) when Cin % 32 == 0 and N*Hout*Wout >= 4096 */
 } VeexGemmDesc;
@@ -102,11 +109,16 @@ typedef struct VeexWgradDesc {
   int32_t nsplit, rows_per_split;
   int32_t bf16;            /* 1: round both operands to bf16 while staging, bf16 MFMA, fp32 accumulate
                               (rows_per_split multiple of 32, Cb % 4 == 0, Cs % 4 == 0) */
+  const void* big_bf16;    /* optional bf16 consumer copies of big / small (BatchNorm already applied to the */
+  const void* small_bf16;  /* activation side): both given + bf16=1 -> copy kernel (rows_per_split % 64 == 0) */
 } VeexWgradDesc;
 int veex_wgrad_gemm(const VeexWgradDesc* d, veexStream_t stream);
 
 /* conv1 of the encoder, Conv2D(64,3,strides=2,'same',relu) on the 40x40x1 map (models.py:219-221). */
 int veex_conv1_fwd(const float* x, const float* w, const float* bias, float* out, int batch, veexStream_t s);
+/* same, also writing the bf16 consumer copy bf16(bn_scale*out + bn_shift) that a bf16 conv2 reads (nullable) */
+int veex_conv1_fwd_bf16(const float* x, const float* w, const float* bias, float* out, const float* bn_scale,
+                        const float* bn_shift, void* out_bf16, int batch, veexStream_t s);
 int veex_conv1_wgrad_blocks(int batch);
 int veex_conv1_wgrad(const float* x, const float* dpre, float* slab /*[blocks][576]*/, int batch, veexStream_t s);
 /* d/dx through conv1 (attribution; no reference call site); mul != NULL gives gradient*input */
@@ -122,6 +134,10 @@ int veex_deconv6_bce_fwd(const float* a5, const float* scale, const float* shift
  * rows 0-3 dW6 partials, rows 4-6 the three column sums of veex_colsum_finalize */
 int veex_deconv6_bwd(const float* dlogit, const float* a5, const float* scale, const float* shift, const float* w6,
                      float* dpre5, float* slab, int batch, veexStream_t s);
+
+/* same, also writing bf16(dpre5) for the bf16 input- and weight-gradient GEMMs of deconv5 (nullable) */
+int veex_deconv6_bwd_bf16(const float* dlogit, const float* a5, const float* scale, const float* shift, const float* w6,
+                          float* dpre5, void* dpre5_bf16, float* slab, int batch, veexStream_t s);
 
 /* sample() (models.py:10-22) fused with the analytic KL term (models.py:161-162).
  * mulv = [B][2L] (z_mean | z_log_var). use_philox=0: eps is read (injected epsilon);

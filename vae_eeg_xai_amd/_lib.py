@@ -31,6 +31,8 @@ class GemmDesc(C.Structure):
         ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad_begin", C.c_int32),
         ("mode", C.c_int32), ("affine_channels", C.c_int32), ("affine_spatial", C.c_int32),
         ("epilogue", C.c_int32), ("relu", C.c_int32), ("e_channels", C.c_int32), ("nsplit", C.c_int32),
+        ("in_bf16", C.c_void_p), ("out_bf16", C.c_void_p), ("out_scale", C.c_void_p), ("out_shift", C.c_void_p),
+        ("out_channels", C.c_int32), ("reserved_", C.c_int32),
         ("weight_bf16", C.c_void_p),
     ]
 
@@ -47,6 +49,7 @@ class WgradDesc(C.Structure):
         ("Hs", C.c_int32), ("Ws", C.c_int32), ("Cs", C.c_int32),
         ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad_begin", C.c_int32),
         ("nsplit", C.c_int32), ("rows_per_split", C.c_int32), ("bf16", C.c_int32),
+        ("big_bf16", C.c_void_p), ("small_bf16", C.c_void_p),
     ]
 
 
@@ -63,11 +66,13 @@ SIGNATURES = {
     "veex_net_set_side_stream": (_I, [_P, _P]),
     "veex_wgrad_gemm": (_I, [C.POINTER(WgradDesc), _P]),
     "veex_conv1_fwd": (_I, [_P, _P, _P, _P, _I, _P]),
+    "veex_conv1_fwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "veex_conv1_wgrad_blocks": (_I, [_I]),
     "veex_conv1_wgrad": (_I, [_P, _P, _P, _I, _P]),
     "veex_conv1_dgrad": (_I, [_P, _P, _P, _P, _I, _P]),
     "veex_deconv6_bce_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P]),
     "veex_deconv6_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "veex_deconv6_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "veex_reparam_kl_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _U, _U, _P]),
     "veex_reparam_kl_bwd": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "veex_bn_prepare": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _F, _P]),

@@ -21,13 +21,19 @@ __device__ __forceinline__ uint4 bload4u(__amdgpu_buffer_rsrc_t r, unsigned off)
   return make_uint4(f[0], f[1], f[2], f[3]);
 }
 
-template <int BM, int BN, int WM, int WN, bool MODE1, int AFF>
+// ABF: A comes from a bf16 consumer copy (p.Abf, BatchNorm already applied by its producer's epilogue):
+// the A tile is staged with plain 16-byte copies -- no affine, no conversion (AFF must be 0).
+template <int BM, int BN, int WM, int WN, bool MODE1, int AFF, bool ABF>
 __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GGParams p) {
   constexpr int BK = 32;
   constexpr int LDKH = BK + 8;         // bf16 elements per LDS row
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 32, NT = WTN / 32;
-  constexpr int APASS = BM / 32;       // A: 8 float4 per row, 32 rows per pass
+  constexpr int AQ = ABF ? 4 : 8;      // 16-byte pieces per A row: 4 x 8 bf16 or 8 x 4 fp32
+  constexpr int ARP = 256 / AQ;        // A rows staged per pass
+  constexpr int APASS = BM / ARP;
+  constexpr int AEB = ABF ? 2 : 4;     // bytes per A element in HBM
+  static_assert(!ABF || AFF == 0, "a bf16 consumer copy already carries the BatchNorm");
   constexpr int BPASS = BN / 64;       // B: 4 x 16 B per row, 64 rows per pass
   constexpr int A_ELEMS = BM * LDKH, B_ELEMS = BN * LDKH;
   static_assert(WM * WN == 4, "4 waves");
@@ -81,7 +87,8 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GGParams p)
   }
 
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.A), 0, (int)((unsigned)p.Nb * p.Hin * p.Win * p.Cin * 4u), 0x00020000);
+      const_cast<void*>(ABF ? p.Abf : static_cast<const void*>(p.A)), 0,
+      (int)((unsigned)p.Nb * p.Hin * p.Win * p.Cin * (unsigned)AEB), 0x00020000);
   const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(p.Wbf), 0, (int)((unsigned)p.kh * p.kw * p.Cin * p.Cout * 2u), 0x00020000);
   const unsigned aff_bytes = (AFF != 0) ? (unsigned)(p.aff_mask + 1) * 4u : 0u;
@@ -90,13 +97,13 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GGParams p)
   const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(AFF != 0 ? p.a_shift : p.A), 0, (int)aff_bytes, 0x00020000);
 
-  // ---- A loader: rows (tid>>3)+32*i, channel quad (tid&7) of the 32-channel chunk ----
-  const int q = tid & 7, lr = tid >> 3;
+  // ---- A loader: rows (tid/AQ)+ARP*i, 16-byte piece (tid%AQ) of the 32-channel chunk ----
+  const int q = tid % AQ, lr = tid / AQ;
   int a_rowbase[APASS], a_nbase[APASS];
   unsigned a_mask[APASS];
 #pragma unroll
   for (int i = 0; i < APASS; ++i) {
-    const int m = m0 + lr + 32 * i;
+    const int m = m0 + lr + ARP * i;
     a_rowbase[i] = 0; a_mask[i] = 0u; a_nbase[i] = 0;
     if (m < Mph) {
       const int n = m / HWp, rem = m - n * HWp;
@@ -105,8 +112,8 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GGParams p)
       int by, bx;   // input pixel read by phase tap (0,0)
       if (MODE1) { by = (oy + p.pb - kys) >> (p.stride - 1); bx = (ox + p.pb - kxs) >> (p.stride - 1); }
       else       { by = p.stride * oy - p.pb; bx = p.stride * ox - p.pb; }
-      a_nbase[i] = n * p.Hin * p.Win * p.Cin * 4;
-      a_rowbase[i] = a_nbase[i] + ((by * p.Win + bx) * p.Cin + 4 * q) * 4;
+      a_nbase[i] = n * p.Hin * p.Win * p.Cin * AEB;
+      a_rowbase[i] = a_nbase[i] + ((by * p.Win + bx) * p.Cin) * AEB + 16 * q;
       unsigned mk = 0u;
       for (int ia = 0; ia < nky; ++ia)
         for (int ib = 0; ib < nkx; ++ib) {
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GGParams p)
     const int tap = (kys + kstep * ia) * p.kw + (kxs + kstep * ib);
     const int ci0 = cc * BK;
     const int dpix = ia * p.Win + ib;
-    const int delta = (MODE1 ? -dpix : dpix) * p.Cin * 4 + ci0 * 4;
+    const int delta = ((MODE1 ? -dpix : dpix) * p.Cin + ci0) * AEB;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
       const bool ok = cvalid && ((a_mask[i] >> tapi) & 1u);
@@ -172,6 +179,10 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GGParams p)
     __bf16* bs = Bs + buf * B_ELEMS;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
+      if constexpr (ABF) {   // 8 bf16 as loaded (out-of-range pieces arrive as zeros)
+        *reinterpret_cast<float4*>(as + (lr + ARP * i) * LDKH + 8 * q) = st.ra[i];
+        continue;
+      }
       float4 v = st.ra[i];
       if (AFF != 0) {
         const float4 sc = st.rsc[AFF == 2 ? i : 0], sh = st.rsh[AFF == 2 ? i : 0];
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GGParams p)
       }
       bf16x4 h;
       h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
-      *reinterpret_cast<bf16x4*>(as + (lr + 32 * i) * LDKH + 4 * q) = h;
+      *reinterpret_cast<bf16x4*>(as + (lr + ARP * i) * LDKH + 4 * q) = h;
     }
 #pragma unroll
     for (int i = 0; i < BPASS; ++i)
@@ -271,9 +282,10 @@ static int ggb_launch(const GGParams& p, dim3 grid, hipStream_t st) {
   constexpr size_t lds = ggb_lds_bytes<BM, BN>();
   static_assert(lds <= 64 * 1024, "fits the default dynamic LDS limit");
   const int aff = (p.a_scale == nullptr) ? 0 : (p.aff_spatial ? 2 : 1);
-  if (aff == 0) hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM, BN, 2, 2, MODE1, 0>), grid, dim3(256), lds, st, p);
-  else if (aff == 1) hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM, BN, 2, 2, MODE1, 1>), grid, dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM, BN, 2, 2, MODE1, 2>), grid, dim3(256), lds, st, p);
+  if (p.Abf != nullptr) hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM, BN, 2, 2, MODE1, 0, true>), grid, dim3(256), lds, st, p);
+  else if (aff == 0) hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM, BN, 2, 2, MODE1, 0, false>), grid, dim3(256), lds, st, p);
+  else if (aff == 1) hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM, BN, 2, 2, MODE1, 1, false>), grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM, BN, 2, 2, MODE1, 2, false>), grid, dim3(256), lds, st, p);
   VEEX_CHECK_LAUNCH();
   return 0;
 }

@@ -37,15 +37,17 @@ __device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[BM 
 
   float* outp = p.Out;
   if (p.epi == VEEX_EPI_RAW) outp += (long long)kz * p.slab_stride;
+  __bf16* const obf = (p.epi == VEEX_EPI_RAW) ? nullptr : reinterpret_cast<__bf16*>(p.OutBf);
 
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int col = n0 + wn * WTN + j * 32 + l31;
     const bool colok = col < p.Cout;
-    float bia = 0.f, esc = 1.f;
+    float bia = 0.f, esc = 1.f, osc = 1.f, osh = 0.f;
     if (colok) {
       if (p.epi == VEEX_EPI_FWD && p.bias != nullptr) bia = p.bias[col];
       if (p.epi == VEEX_EPI_BWD && p.e_scale != nullptr) esc = p.e_scale[col & p.epi_cmask];
+      if (obf != nullptr && p.epi == VEEX_EPI_FWD && p.o_scale != nullptr) { osc = p.o_scale[col & p.o_cmask]; osh = p.o_shift[col & p.o_cmask]; }
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -60,13 +62,16 @@ __device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[BM 
           v += bia;
           if (p.relu) v = fmaxf(v, 0.f);
           outp[addr] = v;
+          if (obf != nullptr) obf[addr] = (__bf16)fmaf(v, osc, osh);
         } else if (p.epi == VEEX_EPI_BWD) {
           const float a = p.aux[addr];
           const bool on = (!p.relu) || (a > 0.f);
           cs1[j] += v;
           cs2[j] = fmaf(v, a, cs2[j]);
           cs3[j] += on ? v : 0.f;
-          outp[addr] = on ? v * esc : 0.f;
+          const float dv = on ? v * esc : 0.f;
+          outp[addr] = dv;
+          if (obf != nullptr) obf[addr] = (__bf16)dv;
         } else {
           outp[addr] = v;
         }

@@ -49,6 +49,11 @@ static int fill_gg(const VeexGemmDesc* d, GGParams& p) {
   if (d == nullptr) { veex_set_error("null descriptor"); return VEEX_EINVAL; }
   memset(&p, 0, sizeof(p));
   p.A = d->in; p.W = d->weight; p.Wbf = d->weight_bf16; p.Out = d->out;
+  p.Abf = d->in_bf16; p.OutBf = d->out_bf16; p.o_scale = d->out_scale; p.o_shift = d->out_shift;
+  if (p.o_scale != nullptr) {
+    if (!pow2_or_zero(d->out_channels) || p.o_shift == nullptr) { veex_set_error("gather_gemm: out_channels must be a power of two and out_shift non-null"); return VEEX_EINVAL; }
+    p.o_cmask = d->out_channels - 1;
+  }
   p.a_scale = d->in_scale; p.a_shift = d->in_shift;
   p.bias = d->bias; p.aux = d->aux; p.e_scale = d->e_scale; p.partials = d->partials;
   p.Nb = d->N; p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin;
@@ -112,6 +117,7 @@ static int fill_wg(const VeexWgradDesc* d, WGParams& p) {
   p.R = p.Nb * p.Hs * p.Ws;
   p.M = p.kh * p.kw * p.Cb;
   p.nsplit = d->nsplit; p.rows_per_split = d->rows_per_split; p.bf16 = d->bf16;
+  p.BigBf = d->big_bf16; p.SmallBf = d->small_bf16;
   if (p.Big == nullptr || p.Small == nullptr || p.Out == nullptr) { veex_set_error("wgrad: null operand"); return VEEX_EINVAL; }
   return 0;
 }
@@ -316,7 +322,7 @@ struct SplitPlan { int nsplit; int per; };  // per = rows_per_split (wgrad) or u
 static SplitPlan wgrad_split(const WGParams& pin) {
   int bm, bn;
   const int tiles = veex_wg_tiles(pin, &bm, &bn);
-  const int bk = pin.bf16 ? 32 : VEEX_BK;   // reduction rows per K chunk of the kernel that will run
+  const int bk = (pin.bf16 == 2) ? 64 : pin.bf16 ? 32 : VEEX_BK;   // reduction rows per K chunk of the kernel that will run
   const int chunks = (pin.R + bk - 1) / bk;
   const int target = veex_env_int("VEEX_WG_BLOCKS", 768);   // blocks per launch the row split aims at
   int ns = (target + tiles - 1) / tiles;
@@ -347,7 +353,9 @@ struct Plan {
   long long d_conv[3], d_h, dmulv, dz, d_dd, g_dd, d_dc[5];
   long long slab, slab_side, partials, losses_tmp;
   long long slab_n, partials_n;
-  long long wpack[7][2];   // bf16 weight copies (floats offset): layers conv2, conv3, deconv1..5; [0] as stored, [1] transposed
+  long long wpack[7][2];
+  // bf16 consumer copies (bf16 compute only; -1 otherwise): BatchNorm-applied activations and gradients
+  long long bf_act_conv[2], bf_act_dd, bf_act_dc[4], bf_d_dc[5], bf_d_conv[3];   // bf16 weight copies (floats offset): layers conv2, conv3, deconv1..5; [0] as stored, [1] transposed
 };
 
 static long long act_floats(const ConvLayer& c, int B) { return (long long)B * c.Hout * c.Hout * c.Cout; }
@@ -356,7 +364,7 @@ static long long act_floats(const ConvLayer& c, int B) { return (long long)B * c
 static void wg_desc_deconv(const VeexNet* n, int i, int B, WGParams& p) {
   const ConvLayer& c = n->dc[i];
   memset(&p, 0, sizeof(p));
-  p.bf16 = (n->compute == VEEX_COMPUTE_BF16);
+  p.bf16 = (n->compute == VEEX_COMPUTE_BF16) ? 2 : 0;   // 2: both operands come as bf16 consumer copies
   p.Nb = B; p.Hb = c.Hout; p.Wb = c.Hout; p.Cb = c.Cout; p.Hs = c.Hin; p.Ws = c.Hin; p.Cs = c.Cin;
   p.kh = c.k; p.kw = c.k; p.stride = c.stride; p.pb = c.pb;
   p.R = B * c.Hin * c.Hin; p.M = c.k * c.k * c.Cout;
@@ -414,7 +422,7 @@ static void make_plan(const VeexNet* n, int B, Plan& P) {
   auto upd = [](long long& m, long long v) { if (v > m) m = v; };
   WGParams wp;
   for (int i = 0; i < 5; ++i) { wg_desc_deconv(n, i, B, wp); upd(slab, (long long)wgrad_split(wp).nsplit * wp.M * wp.Cs); }
-  for (int i = 1; i < 3; ++i) { wg_desc_conv(n->conv[i], B, wp, n->compute == VEEX_COMPUTE_BF16); upd(slab, (long long)wgrad_split(wp).nsplit * wp.M * wp.Cs); }
+  for (int i = 1; i < 3; ++i) { wg_desc_conv(n->conv[i], B, wp, n->compute == VEEX_COMPUTE_BF16 ? 2 : 0); upd(slab, (long long)wgrad_split(wp).nsplit * wp.M * wp.Cs); }
   wg_desc_conv(n->dense, B, wp); upd(slab, (long long)wgrad_split(wp).nsplit * wp.M * wp.Cs);
   wg_desc_conv(n->ddense, B, wp); upd(slab, (long long)wgrad_split(wp).nsplit * wp.M * wp.Cs);
   if (n->variant == VEEX_VARIANT_VAE) {
@@ -443,6 +451,18 @@ static void make_plan(const VeexNet* n, int B, Plan& P) {
   P.slab = w.add("scratch.slab", slab);
   P.slab_side = w.add("scratch.slab_side", slab);   // weight-gradient slabs when they run on the side stream
   P.partials = w.add("scratch.partials", part);
+  P.bf_act_conv[0] = P.bf_act_conv[1] = P.bf_act_dd = -1;
+  for (int i = 0; i < 4; ++i) P.bf_act_dc[i] = -1;
+  for (int i = 0; i < 5; ++i) P.bf_d_dc[i] = -1;
+  for (int i = 0; i < 3; ++i) P.bf_d_conv[i] = -1;
+  if (n->compute == VEEX_COMPUTE_BF16) {
+    auto half = [](long long elems) { return (elems + 1) / 2; };
+    for (int i = 0; i < 2; ++i) P.bf_act_conv[i] = w.add(std::string("bf.act.") + n->conv[i].name, half(act_floats(n->conv[i], B)));
+    P.bf_act_dd = w.add("bf.act.dec.dense", half((long long)B * 4096));
+    for (int i = 0; i < 4; ++i) P.bf_act_dc[i] = w.add(std::string("bf.act.") + n->dc[i].name, half(act_floats(n->dc[i], B)));
+    for (int i = 0; i < 5; ++i) P.bf_d_dc[i] = w.add(std::string("bf.dpre.") + n->dc[i].name, half(act_floats(n->dc[i], B)));
+    for (int i = 1; i < 3; ++i) P.bf_d_conv[i] = w.add(std::string("bf.dpre.") + n->conv[i].name, half(act_floats(n->conv[i], B)));
+  }
   for (int i = 0; i < 7; ++i) {
     const ConvLayer& l = big_layer(n, i);
     const long long halfs = (long long)l.k * l.k * l.Cin * l.Cout;
@@ -511,6 +531,9 @@ static const void* packed_w(const Ctx& c, int i, int fwd) {
   return c.ws + c.plan.wpack[i][which];
 }
 
+// pointer to a bf16 consumer copy region (nullptr in fp32 mode)
+static void* bfp(const Ctx& c, long long off) { return (off < 0) ? nullptr : static_cast<void*>(c.ws + off); }
+
 static int run_bn_prepare(Ctx& c) {
   TRY(run_pack_weights(c));
   const VeexNet* n = c.n;
@@ -520,9 +543,11 @@ static int run_bn_prepare(Ctx& c) {
 
 // forward GEMM layer: in (with producer BN) -> out = relu?(conv + bias)
 static int fwd_gemm(Ctx& c, const ConvLayer& l, int mode, const float* in, int in_bn, int in_bnC, int aff_spatial,
-                    float* out, int relu, const void* wp = nullptr) {
+                    float* out, int relu, const void* wp = nullptr, const void* abf = nullptr, void* outbf = nullptr) {
   GGParams p; memset(&p, 0, sizeof(p));
   p.A = in; p.W = c.P + l.w; p.Wbf = wp; p.Out = out; p.bias = c.P + l.b;
+  p.Abf = abf; p.OutBf = outbf;
+  if (outbf != nullptr && l.bn >= 0) { p.o_scale = c.scale(l.bn); p.o_shift = c.shift(l.bn); p.o_cmask = l.bnC - 1; }
   if (in_bn >= 0) { p.a_scale = c.scale(in_bn); p.a_shift = c.shift(in_bn); p.aff_mask = in_bnC - 1; p.aff_spatial = aff_spatial; }
   p.Nb = c.B; p.Hin = l.Hin; p.Win = l.Hin; p.Cin = l.Cin; p.Hout = l.Hout; p.Wout = l.Hout; p.Cout = l.Cout;
   p.kh = l.k; p.kw = l.k; p.stride = l.stride; p.pb = l.pb; p.mode = mode;
@@ -534,9 +559,12 @@ static int encoder_forward(Ctx& c, const float* x) {
   const VeexNet* n = c.n;
   const Plan& P = c.plan;
   float* ws = c.ws;
-  TRY(veex_conv1_fwd(x, c.P + n->conv[0].w, c.P + n->conv[0].b, ws + P.act_conv[0], c.B, c.st));
-  TRY(fwd_gemm(c, n->conv[1], 0, ws + P.act_conv[0], n->conv[0].bn, 64, 0, ws + P.act_conv[1], 1, packed_w(c, 0, 1)));
-  TRY(fwd_gemm(c, n->conv[2], 0, ws + P.act_conv[1], n->conv[1].bn, 128, 0, ws + P.act_conv[2], 1, packed_w(c, 1, 1)));
+  TRY(veex_conv1_fwd_bf16(x, c.P + n->conv[0].w, c.P + n->conv[0].b, ws + P.act_conv[0], c.scale(n->conv[0].bn),
+                          c.shift(n->conv[0].bn), bfp(c, P.bf_act_conv[0]), c.B, c.st));
+  TRY(fwd_gemm(c, n->conv[1], 0, ws + P.act_conv[0], n->conv[0].bn, 64, 0, ws + P.act_conv[1], 1, packed_w(c, 0, 1),
+               bfp(c, P.bf_act_conv[0]), bfp(c, P.bf_act_conv[1])));
+  TRY(fwd_gemm(c, n->conv[2], 0, ws + P.act_conv[1], n->conv[1].bn, 128, 0, ws + P.act_conv[2], 1, packed_w(c, 1, 1),
+               bfp(c, P.bf_act_conv[1]), nullptr));
   {  // Dense(6400 -> H1, relu) as a 5x5 VALID conv, split-K over taps/channels
     const ConvLayer& l = n->dense;
     GGParams p; memset(&p, 0, sizeof(p));
@@ -569,12 +597,14 @@ static int decoder_trunk(Ctx& c, const float* z) {
   const VeexNet* n = c.n;
   const Plan& P = c.plan;
   float* ws = c.ws;
-  TRY(fwd_gemm(c, n->ddense, 0, z, -1, 0, 0, ws + P.act_dd, 1));
+  TRY(fwd_gemm(c, n->ddense, 0, z, -1, 0, 0, ws + P.act_dd, 1, nullptr, nullptr, bfp(c, P.bf_act_dd)));
   const float* in = ws + P.act_dd;
+  const void* in_bf = bfp(c, P.bf_act_dd);
   int in_bn = n->ddense.bn, in_bnC = 4096, spatial = 1;
   for (int i = 0; i < 5; ++i) {
-    TRY(fwd_gemm(c, n->dc[i], 1, in, in_bn, in_bnC, spatial, ws + P.act_dc[i], 1, packed_w(c, i + 2, 1)));
-    in = ws + P.act_dc[i]; in_bn = n->dc[i].bn; in_bnC = n->dc[i].Cout; spatial = 0;
+    void* out_bf = (i < 4) ? bfp(c, P.bf_act_dc[i]) : nullptr;   // deconv5's consumer (deconv6) reads fp32
+    TRY(fwd_gemm(c, n->dc[i], 1, in, in_bn, in_bnC, spatial, ws + P.act_dc[i], 1, packed_w(c, i + 2, 1), in_bf, out_bf));
+    in = ws + P.act_dc[i]; in_bf = out_bf; in_bn = n->dc[i].bn; in_bnC = n->dc[i].Cout; spatial = 0;
   }
   return 0;
 }
@@ -665,18 +695,21 @@ static int encoder_backward(Ctx& c, const float* x, float* G, int want_param_gra
     p.A = ws + P.d_h; p.W = c.P + n->dense.w;
     p.Nb = c.B; p.Hin = p.Win = p.Hout = p.Wout = 1; p.Cin = H1; p.Cout = 6400;
     p.kh = p.kw = 1; p.stride = 1; p.mode = 1;
+    p.OutBf = bfp(c, P.bf_d_conv[2]);
     TRY(dgrad_bwd(c, p, n->conv[2], ws + P.act_conv[2], ws + P.d_conv[2], G, want_param_grads));
   }
   for (int i = 2; i >= 1; --i) {
     const ConvLayer& l = n->conv[i];
     if (want_param_grads) {
-      WGParams w; wg_desc_conv(l, c.B, w, n->compute == VEEX_COMPUTE_BF16);
+      WGParams w; wg_desc_conv(l, c.B, w, n->compute == VEEX_COMPUTE_BF16 ? 2 : 0);
       w.Big = ws + P.act_conv[i - 1]; w.Small = ws + P.d_conv[i];
+      w.BigBf = bfp(c, P.bf_act_conv[i - 1]); w.SmallBf = bfp(c, P.bf_d_conv[i]);
       w.b_scale = c.scale(n->conv[i - 1].bn); w.b_shift = c.shift(n->conv[i - 1].bn); w.b_aff_mask = n->conv[i - 1].Cout - 1;
       TRY(run_wgrad(c, w, G + l.w));
     }
     GGParams p; memset(&p, 0, sizeof(p));
     p.A = ws + P.d_conv[i]; p.W = c.P + l.w; p.Wbf = packed_w(c, i - 1, 0);
+    p.Abf = bfp(c, P.bf_d_conv[i]); p.OutBf = (i == 2) ? bfp(c, P.bf_d_conv[1]) : nullptr;
     p.Nb = c.B; p.Hin = p.Win = l.Hout; p.Cin = l.Cout; p.Hout = p.Wout = l.Hin; p.Cout = l.Cin;
     p.kh = p.kw = 3; p.stride = 2; p.pb = l.pb; p.mode = 1;
     TRY(dgrad_bwd(c, p, n->conv[i - 1], ws + P.act_conv[i - 1], ws + P.d_conv[i - 1], G, want_param_grads));
@@ -800,8 +833,8 @@ extern "C" int veex_net_train_fwd_bwd(const VeexNet* n, const float* params, con
   // ---- backward (tape.gradient, models.py:166) ----
   {  // deconv6 + BN5/ReLU backward
     const ConvLayer& l5 = n->dc[4];
-    TRY(veex_deconv6_bwd(ws + P.dlogit, ws + P.act_dc[4], c.scale(l5.bn), c.shift(l5.bn), c.P + n->dc[5].w,
-                         ws + P.d_dc[4], ws + P.slab, B, st));
+    TRY(veex_deconv6_bwd_bf16(ws + P.dlogit, ws + P.act_dc[4], c.scale(l5.bn), c.shift(l5.bn), c.P + n->dc[5].w,
+                              ws + P.d_dc[4], bfp(c, P.bf_d_dc[4]), ws + P.slab, B, st));
     TRY(veex_slab_sum(ws + P.slab, B, 448, 256, G + n->dc[5].w, nullptr, 1, 0, st));
     TRY(veex_colsum_finalize(ws + P.slab + 256, B, 448, 64, 64, c.scale(l5.bn), c.mean(l5.bn), c.rstd(l5.bn), G + l5.b,
                              G + n->gamma_off + l5.bn, G + n->beta_off + l5.bn, st));
@@ -813,11 +846,13 @@ extern "C" int veex_net_train_fwd_bwd(const VeexNet* n, const float* params, con
     {  // dW: big = d(pre-act) of this layer, small = its input (with the producer's BN)
       WGParams w; wg_desc_deconv(n, i, B, w);
       w.Big = ws + P.d_dc[i]; w.Small = in;
+      w.BigBf = bfp(c, P.bf_d_dc[i]); w.SmallBf = (i == 0) ? bfp(c, P.bf_act_dd) : bfp(c, P.bf_act_dc[i - 1]);
       w.s_scale = c.scale(prod.bn); w.s_shift = c.shift(prod.bn); w.s_aff_mask = prod.bnC - 1; w.s_aff_spatial = (i == 0);
       TRY(run_wgrad(c, w, G + l.w));
     }
     GGParams p; memset(&p, 0, sizeof(p));
     p.A = ws + P.d_dc[i]; p.W = c.P + l.w; p.Wbf = packed_w(c, i + 2, 0);
+    p.Abf = bfp(c, P.bf_d_dc[i]); p.OutBf = (i > 0) ? bfp(c, P.bf_d_dc[i - 1]) : nullptr;
     p.Nb = B; p.Hin = p.Win = l.Hout; p.Cin = l.Cout; p.Hout = p.Wout = l.Hin; p.Cout = l.Cin;
     p.kh = p.kw = l.k; p.stride = l.stride; p.pb = l.pb; p.mode = 0;
     if (i > 0) {

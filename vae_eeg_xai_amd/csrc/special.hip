@@ -10,6 +10,8 @@
 // results are bitwise reproducible run to run).
 #include "veex_internal.h"
 
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+
 #define IMG 40
 #define C1H 20          // conv1 output 20x20
 #define D5H 39          // deconv5 output 39x39 (deconv6 input)
@@ -27,12 +29,18 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ out,
-                                                        int npix) {
+                                                        int npix, const float* __restrict__ bscale,
+                                                        const float* __restrict__ bshift, __bf16* __restrict__ out_bf) {
   const int cq = threadIdx.x & 15, pg = threadIdx.x >> 4;
   float4 w[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const float4*>(W + t * NCH + 4 * cq);
   const float4 b4 = *reinterpret_cast<const float4*>(bias + 4 * cq);
+  float4 osc = make_float4(1.f, 1.f, 1.f, 1.f), osh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (out_bf != nullptr) {   // bf16 consumer copy: this layer's BatchNorm applied (what conv2 reads)
+    osc = *reinterpret_cast<const float4*>(bscale + 4 * cq);
+    osh = *reinterpret_cast<const float4*>(bshift + 4 * cq);
+  }
   for (int pix = blockIdx.x * 16 + pg; pix < npix; pix += gridDim.x * 16) {
     const int n = pix / (C1H * C1H), rem = pix - n * (C1H * C1H);
     const int oy = rem / C1H, ox = rem - oy * C1H;
@@ -52,6 +60,12 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     }
     acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
     *reinterpret_cast<float4*>(out + (long long)pix * NCH + 4 * cq) = acc;
+    if (out_bf != nullptr) {
+      bf16x4_t h;
+      h[0] = (__bf16)fmaf(acc.x, osc.x, osh.x); h[1] = (__bf16)fmaf(acc.y, osc.y, osh.y);
+      h[2] = (__bf16)fmaf(acc.z, osc.z, osh.z); h[3] = (__bf16)fmaf(acc.w, osc.w, osh.w);
+      *reinterpret_cast<bf16x4_t*>(out_bf + (long long)pix * NCH + 4 * cq) = h;
+    }
   }
 }
 
@@ -244,7 +258,7 @@ __global__ __launch_bounds__(D6_THREADS) void deconv6_bce_fwd_kernel(
 __global__ __launch_bounds__(D6_THREADS) void deconv6_bwd_kernel(
     const float* __restrict__ dlogit, const float* __restrict__ a5, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ W6, float* __restrict__ dpre5,
-    float* __restrict__ slab) {
+    float* __restrict__ slab, __bf16* __restrict__ dpre5_bf) {
   __shared__ __attribute__((aligned(16))) float dl[IMG * IMG];
   __shared__ __attribute__((aligned(16))) float red[(D6_THREADS / 16) * 7 * NCH];
   const int n = blockIdx.x;
@@ -287,6 +301,11 @@ __global__ __launch_bounds__(D6_THREADS) void deconv6_bwd_kernel(
     acc[6].x += o.x; acc[6].y += o.y; acc[6].z += o.z; acc[6].w += o.w;
     o.x *= sc.x; o.y *= sc.y; o.z *= sc.z; o.w *= sc.w;
     *reinterpret_cast<float4*>(dst + pix * NCH + 4 * cq) = o;
+    if (dpre5_bf != nullptr) {
+      bf16x4_t h;
+      h[0] = (__bf16)o.x; h[1] = (__bf16)o.y; h[2] = (__bf16)o.z; h[3] = (__bf16)o.w;
+      *reinterpret_cast<bf16x4_t*>(dpre5_bf + (long long)n * (D5H * D5H * NCH) + pix * NCH + 4 * cq) = h;
+    }
   }
 #pragma unroll
   for (int t = 0; t < 7; ++t) *reinterpret_cast<float4*>(red + (pg * 7 + t) * NCH + 4 * cq) = acc[t];
@@ -569,8 +588,15 @@ static inline int grid_for(long long work, int per_block, int cap) {
 extern "C" {
 
 int veex_conv1_fwd(const float* x, const float* W, const float* bias, float* out, int B, hipStream_t st) {
+  return veex_conv1_fwd_bf16(x, W, bias, out, nullptr, nullptr, nullptr, B, st);
+}
+
+int veex_conv1_fwd_bf16(const float* x, const float* W, const float* bias, float* out, const float* bn_scale,
+                        const float* bn_shift, void* out_bf16, int B, hipStream_t st) {
+  if (out_bf16 != nullptr && (bn_scale == nullptr || bn_shift == nullptr)) { veex_set_error("conv1_fwd: bf16 copy needs the BatchNorm affine"); return -1; }
   const int npix = B * C1H * C1H;
-  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(grid_for(npix, 16, 4096)), dim3(256), 0, st, x, W, bias, out, npix);
+  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(grid_for(npix, 16, 4096)), dim3(256), 0, st, x, W, bias, out, npix, bn_scale,
+                     bn_shift, reinterpret_cast<__bf16*>(out_bf16));
   VEEX_CHECK_LAUNCH();
   return 0;
 }
@@ -602,7 +628,13 @@ int veex_deconv6_bce_fwd(const float* a5, const float* scale, const float* shift
 
 int veex_deconv6_bwd(const float* dlogit, const float* a5, const float* scale, const float* shift, const float* W6,
                       float* dpre5, float* slab, int B, hipStream_t st) {
-  hipLaunchKernelGGL(deconv6_bwd_kernel, dim3(B), dim3(D6_THREADS), 0, st, dlogit, a5, scale, shift, W6, dpre5, slab);
+  return veex_deconv6_bwd_bf16(dlogit, a5, scale, shift, W6, dpre5, nullptr, slab, B, st);
+}
+
+int veex_deconv6_bwd_bf16(const float* dlogit, const float* a5, const float* scale, const float* shift, const float* W6,
+                          float* dpre5, void* dpre5_bf16, float* slab, int B, hipStream_t st) {
+  hipLaunchKernelGGL(deconv6_bwd_kernel, dim3(B), dim3(D6_THREADS), 0, st, dlogit, a5, scale, shift, W6, dpre5, slab,
+                     reinterpret_cast<__bf16*>(dpre5_bf16));
   VEEX_CHECK_LAUNCH();
   return 0;
 }

@@ -42,6 +42,14 @@ struct GGParams {
   int gx, gy, gz;        // logical grid (n tiles, m tiles, k splits), filled by the launcher
   int remap;             // 1: XCD-aware block order (veex_block_coords)
   int tap_inner;         // K-chunk order: 1 = channel chunk outer / tap inner, 0 = tap outer
+  // bf16 "consumer copies" (bf16 compute only): the epilogue can also write what the NEXT bf16 GEMM
+  // reads -- bf16(o_scale[c]*out + o_shift[c]) for a forward launch (this layer's BatchNorm applied),
+  // bf16(out) for a gradient -- and the loader can read such a copy (no affine, no conversion).
+  const void* Abf;       // optional bf16 copy of A (BatchNorm already applied): replaces A / a_scale / a_shift
+  void* OutBf;           // optional bf16 copy of Out
+  const float* o_scale;  // EPI_FWD: BatchNorm of THIS layer for OutBf (nullable: plain rounding)
+  const float* o_shift;
+  int o_cmask;           // o_scale index = col & o_cmask
 };
 
 // ---------------------------------------------------------------------------
@@ -62,6 +70,8 @@ struct WGParams {
   int M;                 // kh*kw*Cb
   int nsplit;
   int bf16;              // 1: bf16 MFMA (operands rounded while staging)
+  const void* BigBf;     // optional bf16 copies [rows][C] of Big / Small (BatchNorm already applied to the
+  const void* SmallBf;   // activation side): staged with 16-byte copies + an in-register 8x8 transpose
   int gx, gy, gz;        // logical grid (m tiles, n tiles, row splits), filled by the launcher
   int remap;
 };
@@ -94,6 +104,10 @@ int veex_gg_bm(const GGParams& p);
 int veex_wg_tiles(const WGParams& p, int* bm, int* bn);
 int veex_wgrad_bf16_ok(const WGParams& p);                       // wgrad_gemm_bf16.hip
 int veex_launch_wgrad_bf16(const WGParams& p, hipStream_t st);
+extern "C" int veex_conv1_fwd_bf16(const float* x, const float* W, const float* bias, float* out, const float* bn_scale,
+                                   const float* bn_shift, void* out_bf16, int B, hipStream_t st);
+extern "C" int veex_deconv6_bwd_bf16(const float* dlogit, const float* a5, const float* scale, const float* shift,
+                                     const float* W6, float* dpre5, void* dpre5_bf16, float* slab, int B, hipStream_t st);
 extern "C" int veex_pack_weights_bf16(const float* src, void* dst, int taps, int rows, int cols, int transpose, hipStream_t st);
 
 void veex_set_error(const char* fmt, ...);

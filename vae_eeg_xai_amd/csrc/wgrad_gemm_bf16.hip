@@ -186,6 +186,185 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WGParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Variant for bf16 consumer copies (WGParams::BigBf / SmallBf, written by the producers' epilogues with
+// the BatchNorm already applied): no affine, no conversion.  A thread stages an 8-row x 8-channel
+// piece: eight 16-byte loads, an in-register 8x8 transpose of 16-bit elements, eight 16-byte k-runs
+// into the [channel][k] LDS tile.  K chunk = 64 rows: waves 0-1 stage Big (16 octets x 8 row groups),
+// waves 2-3 stage Small, every wave multiplies.  LDS rows are 64 bf16 + 8 pad = 144 B = 9 sixteen-byte
+// slots (odd): both the permuted-row writes (rho = e*(T/8) + octet) and the operand reads are
+// conflict-free.
+// ---------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void wgrad_bf16c_kernel(const WGParams p) {
+  constexpr int BK = 64, LDKH = BK + 8;
+  constexpr int WM = 2, WN = 2;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MT = WTM / 32, NT = WTN / 32;
+  constexpr int OM = BM / 8, ON = BN / 8;            // channel octets per tile
+  constexpr int A_ELEMS = BM * LDKH, B_ELEMS = BN * LDKH;
+  static_assert(BM == 128 && (BN == 128 || BN == 64), "waves 0-1 stage A, waves 2-3 stage B");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* As = reinterpret_cast<__bf16*>(smem_raw);      // [2][BM][72]
+  __bf16* Bs = As + 2 * A_ELEMS;                         // [2][BN][72]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int lh = lane >> 5, l31 = lane & 31;
+
+  int bmt, bnt, kz;
+  veex_block_coords(p.remap, p.gx, p.gy, bmt, bnt, kz);
+  const int m0 = bmt * BM, n0 = bnt * BN;
+  const int r_begin = kz * p.rows_per_split;
+  const int r_end = min(p.R, r_begin + p.rows_per_split);
+  const int nchunks = (r_end > r_begin) ? (r_end - r_begin + BK - 1) / BK : 0;
+
+  const bool isA = wave < 2;
+  const int u = isA ? tid : tid - 128;
+  const int OT = isA ? OM : ON;
+  const int oct = u % OT, rg = u / OT;                   // channel octet, 8-row group
+  const bool active = rg < 8;                            // BN = 64: wave 3 has nothing to stage
+  const int ch0 = (isA ? m0 : n0) + 8 * oct;
+  int C, H, W, str, pb, ky = 0, kx = 0, cch;
+  bool ch_ok;
+  if (isA) {
+    C = p.Cb; H = p.Hb; W = p.Wb; str = p.stride; pb = p.pb;
+    ch_ok = active && ch0 < p.M;
+    const int tap = ch0 / p.Cb;
+    cch = ch0 - tap * p.Cb;
+    ky = tap / p.kw; kx = tap - ky * p.kw;
+  } else {
+    C = p.Cs; H = p.Hs; W = p.Ws; str = 1; pb = 0;
+    ch_ok = active && ch0 < p.Cs;
+    cch = ch0;
+  }
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(isA ? p.BigBf : p.SmallBf), 0,
+      (int)(isA ? (unsigned)p.Nb * p.Hb * p.Wb * p.Cb * 2u : (unsigned)p.R * p.Cs * 2u), 0x00020000);
+  const int HWs = p.Hs * p.Ws;
+  const float invHWs = 1.0f / (float)HWs, invWs = 1.0f / (float)p.Ws;
+  __bf16* const lds_dst = (isA ? As : Bs) + oct * LDKH + 8 * rg;     // + buf*ELEMS + e*OT*LDKH
+  const int lds_estride = OT * LDKH;
+  const int lds_elems = isA ? A_ELEMS : B_ELEMS;
+
+  v4u ra[8];
+
+  auto load_chunk = [&](int c) {
+    const int r0 = r_begin + c * BK + 8 * rg;
+    int n, py, px;
+    {
+      int q1 = (int)((float)r0 * invHWs); int m1 = r0 - q1 * HWs;
+      if (m1 < 0) { q1 -= 1; m1 += HWs; }
+      if (m1 >= HWs) { q1 += 1; m1 -= HWs; }
+      n = q1;
+      int q2 = (int)((float)m1 * invWs); int m2 = m1 - q2 * p.Ws;
+      if (m2 < 0) { q2 -= 1; m2 += p.Ws; }
+      if (m2 >= p.Ws) { q2 += 1; m2 -= p.Ws; }
+      py = q2; px = m2;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int by = str * py + ky - pb, bx = str * px + kx - pb;
+      const bool ok = ch_ok && (r0 + k) < r_end && by >= 0 && by < H && bx >= 0 && bx < W;
+      ra[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? (unsigned)((((n * H + by) * W + bx) * C + cch) * 2) : VEEX_OOB, 0, 0);
+      px += 1;
+      if (px == p.Ws) { px = 0; py += 1; if (py == p.Hs) { py = 0; n += 1; } }
+    }
+  };
+
+  // ra[k][d] = channels (2d, 2d+1) of row k  ->  per channel the 8 rows as four dwords (k0k1, k2k3, k4k5, k6k7)
+  auto store_chunk = [&](int buf) {
+    if (!active) return;
+    __bf16* d = lds_dst + buf * lds_elems;
+#pragma unroll
+    for (int dp = 0; dp < 4; ++dp) {
+      v4u lo, hi;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned a = ra[2 * j][dp], b = ra[2 * j + 1][dp];
+        lo[j] = (a & 0xFFFFu) | (b << 16);
+        hi[j] = (a >> 16) | (b & 0xFFFF0000u);
+      }
+      *reinterpret_cast<v4u*>(d + (2 * dp) * lds_estride) = lo;
+      *reinterpret_cast<v4u*>(d + (2 * dp + 1) * lds_estride) = hi;
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  for (int c = 0; c < nchunks; ++c) {
+    const int cur = c & 1;
+    load_chunk(c + 1);  // past the end: out-of-range offsets -> zeros, never read
+    const __bf16* as = As + cur * A_ELEMS + (wm * WTM + l31) * LDKH + 8 * lh;
+    const __bf16* bs = Bs + cur * B_ELEMS + (wn * WTN + l31) * LDKH + 8 * lh;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 av[MT], bv[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) av[i] = *reinterpret_cast<const bf16x8*>(as + i * 32 * LDKH + 16 * ks);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(bs + j * 32 * LDKH + 16 * ks);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    store_chunk(cur ^ 1);
+    __syncthreads();
+  }
+
+  // tile row rho -> channel 8*(rho % (T/8)) + rho / (T/8)
+  float* outp = p.Out + (long long)kz * p.M * p.Cs;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int rn = wn * WTN + j * 32 + l31;
+    const int col = n0 + 8 * (rn % ON) + rn / ON;
+    if (col >= p.Cs) continue;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rm = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int m = m0 + 8 * (rm % OM) + rm / OM;
+        if (m < p.M) outp[(long long)m * p.Cs + col] = acc[i][j][r];
+      }
+    }
+  }
+}
+
+template <int BM, int BN>
+static int wgbc_launch(const WGParams& pin, hipStream_t st) {
+  WGParams p = pin;
+  p.gx = (p.M + BM - 1) / BM; p.gy = (p.Cs + BN - 1) / BN; p.gz = p.nsplit;
+  p.remap = veex_env_int("VEEX_XCD_WG", 0);
+  dim3 grid((unsigned)p.gx * p.gy * p.gz, 1, 1);
+  constexpr size_t lds = 2 * (BM + BN) * 72 * 2;
+  static bool attr_done = false;
+  if (!attr_done && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16c_kernel<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      veex_set_error("wgrad(bf16): cannot raise the dynamic LDS limit to %zu bytes", lds); return -3;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((wgrad_bf16c_kernel<BM, BN>), grid, dim3(256), lds, st, p);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
 template <int BM, int BN>
 static int wgb_launch(const WGParams& pin, hipStream_t st) {
   WGParams p = pin;
@@ -203,14 +382,25 @@ static int wgb_launch(const WGParams& pin, hipStream_t st) {
 }
 
 // 1 if the bf16 kernel can run this (validated) descriptor, else the caller uses the fp32 kernel
+int veex_wgrad_bf16c_ok(const WGParams& p);
 int veex_wgrad_bf16_ok(const WGParams& p) {
+  if (veex_wgrad_bf16c_ok(p)) return 1;
   const long long big_bytes = (long long)p.Nb * p.Hb * p.Wb * p.Cb * 4, small_bytes = (long long)p.R * p.Cs * 4;
   return p.bf16 && p.M >= 128 && p.Cs >= 64 && (p.Cb % 4 == 0) && (p.Cs % 4 == 0) && (p.rows_per_split % 32 == 0) &&
          big_bytes < 0x7FFF0000LL && small_bytes < 0x7FFF0000LL && p.R < (1 << 24) &&
          !(p.b_scale != nullptr && p.b_aff_spatial) && !(p.s_scale != nullptr && p.s_aff_spatial);
 }
 
+// 1 if both operands come as bf16 consumer copies the copy kernel can take
+int veex_wgrad_bf16c_ok(const WGParams& p) {
+  const long long big_bytes = (long long)p.Nb * p.Hb * p.Wb * p.Cb * 2, small_bytes = (long long)p.R * p.Cs * 2;
+  return p.bf16 && p.BigBf != nullptr && p.SmallBf != nullptr && p.M >= 128 && p.Cs >= 64 && (p.Cb % 8 == 0) &&
+         (p.Cs % 8 == 0) && (p.rows_per_split % 64 == 0) && big_bytes < 0x7FFF0000LL && small_bytes < 0x7FFF0000LL &&
+         p.R < (1 << 24);
+}
+
 int veex_launch_wgrad_bf16(const WGParams& p, hipStream_t st) {
+  if (veex_wgrad_bf16c_ok(p)) return (p.Cs > 64) ? wgbc_launch<128, 128>(p, st) : wgbc_launch<128, 64>(p, st);
   if (p.Cs > 64) return wgb_launch<128, 128>(p, st);
   return wgb_launch<128, 64>(p, st);
 }

@@ -77,11 +77,22 @@ def gemm_cases(B, bf16=False):
     keep = []
 
     def gg(label, macs, mode, A, W, out, N, Hin, Cin, Hout, Cout, k, stride, pb, aff=None, spatial=0, epi=0,
-           aux=None, esc=None, wbf=None):
+           aux=None, esc=None, wbf=None, osc=None):
         d = GemmDesc()
         d.inp, d.weight, d.out = A.data_ptr(), W.data_ptr(), out.data_ptr()
         if wbf is not None:
             keep.append(wbf); d.weight_bf16 = wbf.data_ptr()
+            # bf16 consumer copies as the network uses them: A with its BatchNorm applied, Out copy for the next layer
+            if aff is not None and not spatial:
+                abf = (A * aff[0] + aff[1]).to(torch.bfloat16)
+            elif aff is not None:
+                abf = (A.reshape(N, -1) * aff[0] + aff[1]).reshape(A.shape).to(torch.bfloat16)
+            else:
+                abf = A.to(torch.bfloat16)
+            obf = torch.empty(out.shape, dtype=torch.bfloat16, device="cuda")
+            keep.extend([abf, obf]); d.in_bf16, d.out_bf16 = abf.data_ptr(), obf.data_ptr()
+            if osc is not None:
+                keep.append(osc); d.out_scale, d.out_shift, d.out_channels = osc[0].data_ptr(), osc[1].data_ptr(), osc[0].numel()
         if aff is not None:
             d.in_scale, d.in_shift, d.affine_channels, d.affine_spatial = aff[0].data_ptr(), aff[1].data_ptr(), aff[0].numel(), spatial
         if epi == 0:
@@ -116,8 +127,13 @@ def gemm_cases(B, bf16=False):
         R = N * Hs * Hs
         M = k * k * Cb
         tiles = ((M + 127) // 128) * ((Cs + 127) // 128 if Cs > 64 else 1)
-        bk = 32 if bf16 else 16
+        bk = 64 if bf16 else 16
         d.bf16 = 1 if bf16 else 0
+        if bf16:
+            bb = (big * aff_big[0] + aff_big[1]) if aff_big is not None else big
+            sb = (small * aff_small[0] + aff_small[1]) if aff_small is not None else small
+            bb, sb = bb.to(torch.bfloat16), sb.to(torch.bfloat16)
+            keep.extend([bb, sb]); d.big_bf16, d.small_bf16 = bb.data_ptr(), sb.data_ptr()
         chunks = (R + bk - 1) // bk
         ns = max(1, min((768 + tiles - 1) // tiles, max(chunks // 4, 1)))
         cps = (chunks + ns - 1) // ns
@@ -135,7 +151,8 @@ def gemm_cases(B, bf16=False):
         aff = (torch.rand(cin, device="cuda") + 0.5, _rand(cin))
         dy = _rand(B, hout, hout, cout); dx = torch.empty_like(x)
         wt, wa = (_pack(W, 1), _pack(W, 0)) if bf16 else (None, None)
-        cases.append(gg(f"{name}.fwd", macs * B, 0, x, W, y, B, hin, cin, hout, cout, k, s, pb, aff=aff, wbf=wt))
+        oaff = (torch.rand(cout, device="cuda") + 0.5, _rand(cout))
+        cases.append(gg(f"{name}.fwd", macs * B, 0, x, W, y, B, hin, cin, hout, cout, k, s, pb, aff=aff, wbf=wt, osc=oaff))
         cases.append(gg(f"{name}.dgrad", macs * B, 1, dy, W, dx, B, hout, cout, hin, cin, k, s, pb, epi=1, aux=x,
                         esc=aff[0], wbf=wa))
         cases.append(wg(f"{name}.wgrad", macs * B, x, dy, B, hin, cin, hout, cout, k, s, pb, aff_big=aff))
@@ -147,14 +164,16 @@ def gemm_cases(B, bf16=False):
         aff = (torch.rand(nch, device="cuda") + 0.5, _rand(nch))
         dy = _rand(B, hout, hout, cout); dx = torch.empty_like(x)
         wt, wa = (_pack(W, 1), _pack(W, 0)) if bf16 else (None, None)
-        cases.append(gg(f"{name}.fwd", macs * B, 1, x, W, y, B, hin, cin, hout, cout, k, s, pb, aff=aff, spatial=spatial, wbf=wa))
+        oaff = (torch.rand(cout, device="cuda") + 0.5, _rand(cout))
+        cases.append(gg(f"{name}.fwd", macs * B, 1, x, W, y, B, hin, cin, hout, cout, k, s, pb, aff=aff, spatial=spatial, wbf=wa, osc=oaff))
         if spatial:
             cases.append(gg(f"{name}.dgrad", macs * B, 0, dy, W, dx, B, hout, cout, hin, cin, k, s, pb, wbf=wt))
         else:
             cases.append(gg(f"{name}.dgrad", macs * B, 0, dy, W, dx, B, hout, cout, hin, cin, k, s, pb, epi=1, aux=x,
                             esc=aff[0], wbf=wt))
-        if not spatial:
-            cases.append(wg(f"{name}.wgrad", macs * B, dy, x, B, hout, cout, hin, cin, k, s, pb, aff_small=aff))
+        if not spatial or bf16:
+            cases.append(wg(f"{name}.wgrad", macs * B, dy, x, B, hout, cout, hin, cin, k, s, pb,
+                            aff_small=None if spatial else aff))
     gemm_cases._keep = keep
     return cases
 
