@@ -13,7 +13,7 @@ class GGParams(C.Structure):
                 ("aff_mask", C.c_int), ("aff_spatial", C.c_int), ("epi", C.c_int), ("relu", C.c_int), ("epi_cmask", C.c_int),
                 ("nsplit", C.c_int), ("chunks_per_split", C.c_int), ("nphase", C.c_int), ("tile_prefix", C.c_int * 5),
                 ("Hp", C.c_int * 2), ("Wp", C.c_int * 2), ("o0", C.c_int * 2), ("slab_stride", C.c_longlong), ("gx", C.c_int), ("gy", C.c_int), ("gz", C.c_int), ("remap", C.c_int), ("tap_inner", C.c_int),
-                ("Abf", C.c_void_p), ("OutBf", C.c_void_p), ("o_scale", C.c_void_p), ("o_shift", C.c_void_p), ("o_cmask", C.c_int)]
+                ("Abf", C.c_void_p), ("OutBf", C.c_void_p), ("o_scale", C.c_void_p), ("o_shift", C.c_void_p), ("o_cmask", C.c_int), ("dbg", C.c_int)]
 
 raw = C.CDLL(_lib.LIB_PATH)
 fn = raw.veexi_debug_gather_gemm

@@ -8,6 +8,8 @@ O=gpurun_out/$R
 mkdir -p $O
 timeout -k 10 300 python bench.py --steps 50 --warmup 10 > $O/bench.json 2> $O/bench.err
 timeout -k 10 120 python -m vae_eeg_xai_amd.roofline 512 > $O/layer_table.txt 2>/dev/null
+timeout -k 10 300 python bench.py --dtype bf16 --steps 50 --warmup 10 --no-cpu-baseline > $O/bench_bf16.json 2> $O/bench_bf16.err
+timeout -k 10 120 python -m vae_eeg_xai_amd.roofline 512 bf16 > $O/layer_table_bf16.txt 2>/dev/null
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-attribution > $O/trace.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python tools/prof_gemms.py 512 2 > $O/pmc_fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python tools/prof_gemms.py 512 2 > $O/pmc_write.log 2>&1

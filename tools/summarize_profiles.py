@@ -11,6 +11,9 @@ src, dst = f"gpurun_out/{R}", "profiles"
 os.makedirs(dst, exist_ok=True)
 shutil.copy(f"{src}/bench.json", f"{dst}/{R}_bench.json")
 shutil.copy(f"{src}/layer_table.txt", f"{dst}/{R}_layer_table.txt")
+for extra in ("bench_bf16.json", "layer_table_bf16.txt"):
+    if os.path.exists(f"{src}/{extra}"):
+        shutil.copy(f"{src}/{extra}", f"{dst}/{R}_{extra}")
 ks = newest(f"{src}/trace/*/*kernel_stats.csv")
 shutil.copy(ks, f"{dst}/{R}_kernel_stats.csv")
 with open(f"{dst}/{R}_kernel_stats.txt", "w") as f:

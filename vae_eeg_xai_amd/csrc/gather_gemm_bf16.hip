@@ -21,6 +21,17 @@ __device__ __forceinline__ uint4 bload4u(__amdgpu_buffer_rsrc_t r, unsigned off)
   return make_uint4(f[0], f[1], f[2], f[3]);
 }
 
+// q = r / d, rem = r % d for 0 <= r < 2^24, 1 <= d < 2^24 (float reciprocal + one correction step: a
+// fraction of the ~45 instructions of a 32-bit integer division, which matter here because a bf16 tile's
+// whole K loop is only a few thousand cycles)
+__device__ __forceinline__ void fdivmod24(int r, int d, float inv, int& qo, int& rem) {
+  int q = (int)((float)r * inv);
+  int m = r - q * d;
+  if (m < 0) { q -= 1; m += d; }
+  if (m >= d) { q += 1; m -= d; }
+  qo = q; rem = m;
+}
+
 // ABF: A comes from a bf16 consumer copy (p.Abf, BatchNorm already applied by its producer's epilogue):
 // the A tile is staged with plain 16-byte copies -- no affine, no conversion (AFF must be 0).
 template <int BM, int BN, int WM, int WN, bool MODE1, int AFF, bool ABF>
@@ -75,12 +86,14 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GGParams p)
   const int c_begin = kz * p.chunks_per_split;
   const int c_end = min(nchunks, c_begin + p.chunks_per_split);
   const int HWp = Hp * Wp;
+  const float invHWp = 1.0f / (float)HWp, invWp = 1.0f / (float)Wp;   // rows < 2^24 (checked by the launcher)
 
   if (tid < BM) {
     int m = m0 + tid, off = -1;
     if (m < Mph) {
-      int n = m / HWp, rem = m - n * HWp;
-      int j = rem / Wp, i = rem - j * Wp;
+      int n, rem, j, i;
+      fdivmod24(m, HWp, invHWp, n, rem);
+      fdivmod24(rem, Wp, invWp, j, i);
       off = (n * p.Hout + ostep * j + oy0) * p.Wout + ostep * i + ox0;
     }
     s_off[tid] = off;
@@ -106,8 +119,9 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GGParams p)
     const int m = m0 + lr + ARP * i;
     a_rowbase[i] = 0; a_mask[i] = 0u; a_nbase[i] = 0;
     if (m < Mph) {
-      const int n = m / HWp, rem = m - n * HWp;
-      const int j = rem / Wp, ii = rem - j * Wp;
+      int n, rem, j, ii;
+      fdivmod24(m, HWp, invHWp, n, rem);
+      fdivmod24(rem, Wp, invWp, j, ii);
       const int oy = ostep * j + oy0, ox = ostep * ii + ox0;
       int by, bx;   // input pixel read by phase tap (0,0)
       if (MODE1) { by = (oy + p.pb - kys) >> (p.stride - 1); bx = (ox + p.pb - kxs) >> (p.stride - 1); }
@@ -231,15 +245,27 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GGParams p)
   store_chunk(s0, 0);
   load_chunk(s0, c_begin + 1, c_begin + 1 < c_end);
   __syncthreads();
+  const int dbg = p.dbg;   // timing-only: 1 no global loads in the loop, 2 no MFMA, 4 no barrier, 8 no LDS store, 16 no epilogue
   for (int c = c_begin; c < c_end; c += 2) {
-    load_chunk(s1, c + 2, c + 2 < c_end);
-    compute(0);
-    store_chunk(s0, 1);
-    __syncthreads();
-    load_chunk(s0, c + 3, c + 3 < c_end);
-    compute(1);
-    store_chunk(s1, 0);
-    __syncthreads();
+    if (!(dbg & 1)) load_chunk(s1, c + 2, c + 2 < c_end);
+    if (!(dbg & 2)) compute(0);
+    if (!(dbg & 8)) store_chunk(s0, 1);
+    if (!(dbg & 4)) __syncthreads();
+    if (!(dbg & 1)) load_chunk(s0, c + 3, c + 3 < c_end);
+    if (!(dbg & 2)) compute(1);
+    if (!(dbg & 8)) store_chunk(s1, 0);
+    if (!(dbg & 4)) __syncthreads();
+  }
+  if (dbg & 16) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+    if (t == 1.2345f) p.Out[tid] = t;   // keeps the accumulators alive
+    return;
   }
   gg_epilogue<BM, BN, WM, WN>(p, acc, s_off, reinterpret_cast<float*>(As), btile, kz, n0);
 }
@@ -293,6 +319,7 @@ static int ggb_launch(const GGParams& p, dim3 grid, hipStream_t st) {
 // p: validated by veex_launch_gather_gemm, phase tables filled (veex_gg_m_tiles), p.Wbf != nullptr
 int veex_launch_gather_gemm_bf16(GGParams& p, int mtiles, hipStream_t st) {
   if (p.Cin % 32 != 0) { veex_set_error("gather_gemm(bf16): Cin %% 32 == 0 required (got %d)", p.Cin); return -1; }
+  if ((long long)p.Nb * p.Hout * p.Wout >= (1LL << 24)) { veex_set_error("gather_gemm(bf16): more than 2^24 output pixels"); return -1; }
   const int bm = veex_gg_bm(p);
   const int bn = (bm == 128 && p.Cout > 64) ? 128 : 64;
   const int ntiles = (p.Cout + bn - 1) / bn;
@@ -303,6 +330,7 @@ int veex_launch_gather_gemm_bf16(GGParams& p, int mtiles, hipStream_t st) {
   const int xr = veex_env_int("VEEX_XCD", -1);
   p.remap = (xr < 0) ? (p.nphase == 1) : xr;
   p.tap_inner = veex_env_int("VEEX_TAPIN", 1);
+  p.dbg = veex_env_int("VEEX_DBG", 0);
   p.gx = ntiles; p.gy = mtiles; p.gz = p.nsplit;
   dim3 grid((unsigned)ntiles * mtiles * p.nsplit, 1, 1);
   if (bm == 64) return (p.mode == 1) ? ggb_launch<64, 64, true>(p, grid, st) : ggb_launch<64, 64, false>(p, grid, st);

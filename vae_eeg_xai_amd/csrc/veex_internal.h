@@ -50,6 +50,7 @@ struct GGParams {
   const float* o_scale;  // EPI_FWD: BatchNorm of THIS layer for OutBf (nullable: plain rounding)
   const float* o_shift;
   int o_cmask;           // o_scale index = col & o_cmask
+  int dbg;               // timing-only switches of the bf16 engine (VEEX_DBG; results are wrong when non-zero)
 };
 
 // ---------------------------------------------------------------------------
