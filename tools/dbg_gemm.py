@@ -34,7 +34,7 @@ for label, args in [("deconv4.fwd   (mode1 64x64 aff)  ", (1, 17, 128, 19, 64, 3
                     ("deconv4.dgrad (mode0 64x64)      ", (0, 19, 64, 17, 128, 3, 1, 0, False)),
                     ("deconv2.dgrad (mode0 64x64 C=128)", (0, 8, 128, 8, 256, 3, 1, 1, False))]:
     p, keep = case(*args)
-    for dbg, nm in [(0, "full"), (16, "no-epilogue"), (1, "no-gload"), (17, "no-gload, no-epilogue"), (13, "mfma+ldsread only"), (29, "mfma+ldsread, no-epilogue")]:
+    for dbg, nm in [(0, "full"), (16, "no-epilogue"), (64, "A loads hit 4KiB"), (1, "no-gload"), (17, "no-gload, no-epilogue"), (13, "mfma+ldsread only"), (29, "mfma+ldsread, no-epilogue")]:
         t = _time_launch(lambda: fn(C.byref(p), dbg, _lib.current_stream()), iters=10)
         print(f"{label} {nm:26s} {t*1e6:8.1f} us")
 pk = raw.veexi_debug_mfma_peak; pk.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]; pk.restype = C.c_int

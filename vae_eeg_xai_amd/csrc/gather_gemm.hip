@@ -254,7 +254,11 @@ __global__ __launch_bounds__(256) void gather_gemm_generic_kernel(const GGParams
 //    (row, tap) pair is one bit of a per-row mask computed once before the loop.
 // AFF: 0 none, 1 per-channel producer BatchNorm, 2 BatchNorm over the flattened (h,w,c) vector.
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool MODE1, int AFF, int BK, int DBG = 0>
+// V2: the chunk -> (tap, channel slice) decomposition is carried incrementally in scalar registers (no
+// integer division in the K loop: -2 % over the GEMMs of a step).  Tried on top of it and dropped (batch 512,
+// tools/ab_env.py): the per-channel BatchNorm staged in LDS (+1 %), s_setprio around the MFMAs (+2 %), channel-
+// slice pairs innermost for L1 line re-use (-0.5 %).
+template <int BM, int BN, int WM, int WN, bool MODE1, int AFF, int BK, int DBG = 0, int V2 = 0>
 __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 32, NT = WTN / 32;
@@ -309,7 +313,6 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
   const int c_begin = kz * p.chunks_per_split;
   const int c_end = (DBG & 32) ? c_begin : min(nchunks, c_begin + p.chunks_per_split);
   const int HWp = Hp * Wp;
-
   if (tid < BM) {
     int m = m0 + tid, off = -1;
     if (m < Mph) {
@@ -382,10 +385,25 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
     bool rok[APASS];
   };
 
+  // V2: running (tap, channel slice) of the next chunk to load; chunks are loaded strictly in order
+  int it_c = c_begin, it_cc = 0, it_tapi = 0, it_ia = 0, it_ib = 0;
+  if (V2) {
+    it_cc = c_begin / ntaps; it_tapi = c_begin - it_cc * ntaps;
+    it_ia = it_tapi / nkx; it_ib = it_tapi - it_ia * nkx;
+  }
+
   auto load_chunk = [&](Stage& st, int c, bool cvalid) {
-    const int cc = p.tap_inner ? c / ntaps : c % cpt;   // see the generic kernel
-    const int tapi = p.tap_inner ? c - cc * ntaps : c / cpt;
-    const int ia = tapi / nkx, ib = tapi - ia * nkx;
+    int cc, tapi, ia, ib;
+    if (V2) {
+      cc = it_cc; tapi = it_tapi; ia = it_ia; ib = it_ib; cvalid = it_c < c_end;
+      ++it_c; ++it_tapi; ++it_ib;
+      if (it_ib == nkx) { it_ib = 0; ++it_ia; }
+      if (it_tapi == ntaps) { it_tapi = 0; it_ia = 0; it_ib = 0; ++it_cc; }
+    } else {
+      cc = p.tap_inner ? c / ntaps : c % cpt;   // see the generic kernel
+      tapi = p.tap_inner ? c - cc * ntaps : c / cpt;
+      ia = tapi / nkx; ib = tapi - ia * nkx;
+    }
     const int tap = (kys + kstep * ia) * p.kw + (kxs + kstep * ib);
     const int ci0 = cc * BK;
     const int dpix = ia * p.Win + ib;
@@ -394,7 +412,8 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
       const bool ok = kq && ((a_mask[i] >> tapi) & 1u);
-      const unsigned off = ok ? (unsigned)(a_rowbase[i] + delta) : VEEX_OOB;
+      unsigned off = ok ? (unsigned)(a_rowbase[i] + delta) : VEEX_OOB;
+      if (DBG & 64) off = ok ? (off & 0xFF0u) : VEEX_OOB;   // timing-only: every A load hits the same 4 KiB
       st.ra[i] = bload4(rA, off);
       st.rok[i] = ok;
       if (AFF == 2) {
@@ -600,6 +619,17 @@ static int gg_launch_fast(const GGParams& p, dim3 grid, hipStream_t st) {
         gg_set_lds(gather_gemm_kernel<BM, BN, 2, 2, MODE1, 2, BK>, lds)) return -3;
     attr_done = true;
   }
+  if constexpr (BM == 64 && BN == 64 && BK == 16) {
+    // V2 (see the kernel); VEEX_GGV2=0 keeps the first version for A/B timing
+    const int v2 = veex_env_int("VEEX_GGV2", 1);
+    if (v2 >= 1) {
+      if (aff == 0) hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 2, 2, MODE1, 0, BK, 0, 1>), grid, dim3(256), lds, st, p);
+      else if (aff == 1) hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 2, 2, MODE1, 1, BK, 0, 1>), grid, dim3(256), lds, st, p);
+      else hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 2, 2, MODE1, 2, BK, 0, 1>), grid, dim3(256), lds, st, p);
+      VEEX_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   if (aff == 0) hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 2, 2, MODE1, 0, BK>), grid, dim3(256), lds, st, p);
   else if (aff == 1) hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 2, 2, MODE1, 1, BK>), grid, dim3(256), lds, st, p);
   else hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 2, 2, MODE1, 2, BK>), grid, dim3(256), lds, st, p);
@@ -669,6 +699,7 @@ int veex_launch_gather_gemm(const GGParams& pin, hipStream_t st) {
   const bool fast = vec_ok && a_bytes < 0x7FFF0000LL && w_bytes < 0x7FFF0000LL && p.kh * p.kw <= 32 &&
                     (p.a_scale == nullptr || !p.aff_spatial || (p.aff_mask + 1) == p.Hin * p.Win * p.Cin);
   if (p.Wbf != nullptr && fast && Mtot >= 4096 && Mtot < (1LL << 24) && p.Cin % 32 == 0) return veex_launch_gather_gemm_bf16(p, mtiles, st);
+  if (bm == 64 && fast && veex_env_int("VEEX_GGV3", 1) && veex_gg_v3_ok(p)) return veex_launch_gather_gemm_v3(p, mtiles, st);
   if (bm == 128 && bn == 128 && fast) return gg_launch_cfg<128, 128>(p, mtiles, true, st);
   if (bm == 128 && bn == 64 && fast) return gg_launch_cfg<128, 64>(p, mtiles, true, st);
   if (bm == 64 && fast) return gg_launch_cfg<64, 64>(p, mtiles, true, st);
@@ -707,7 +738,7 @@ extern "C" int veexi_debug_mfma_peak(float* out, int blocks, int iters, hipStrea
 }
 
 #define DBG_CASE(BM_, BN_, M1_, AFF_, D_) \
-  case D_: hipLaunchKernelGGL((gather_gemm_kernel<BM_, BN_, 2, 2, M1_, AFF_, 16, D_>), grid, dim3(256), lds, st, p); break;
+  case D_: hipLaunchKernelGGL((gather_gemm_kernel<BM_, BN_, 2, 2, M1_, AFF_, 16, D_, 1>), grid, dim3(256), lds, st, p); break;
 
 // Timing-only variants for profiling (outputs are wrong by construction). dbg bits: 1 = no global loads in
 // the K loop, 2 = no MFMA, 4 = no barrier, 8 = no LDS store, 16 = no epilogue.  64x64 tiles: mode 1 with a
@@ -722,13 +753,13 @@ extern "C" int veexi_debug_gather_gemm(const GGParams* pin, int dbg, hipStream_t
   constexpr size_t lds = gg_lds_bytes<64, 64, true, 16>();
   if (p.mode == 1) {
     switch (dbg) {
-      DBG_CASE(64, 64, true, 1, 0) DBG_CASE(64, 64, true, 1, 1) DBG_CASE(64, 64, true, 1, 16)
+      DBG_CASE(64, 64, true, 1, 0) DBG_CASE(64, 64, true, 1, 1) DBG_CASE(64, 64, true, 1, 16) DBG_CASE(64, 64, true, 1, 64)
       DBG_CASE(64, 64, true, 1, 13) DBG_CASE(64, 64, true, 1, 29) DBG_CASE(64, 64, true, 1, 17)
       default: return -1;
     }
   } else {
     switch (dbg) {
-      DBG_CASE(64, 64, false, 0, 0) DBG_CASE(64, 64, false, 0, 1) DBG_CASE(64, 64, false, 0, 16)
+      DBG_CASE(64, 64, false, 0, 0) DBG_CASE(64, 64, false, 0, 1) DBG_CASE(64, 64, false, 0, 16) DBG_CASE(64, 64, false, 0, 64)
       DBG_CASE(64, 64, false, 0, 13) DBG_CASE(64, 64, false, 0, 29) DBG_CASE(64, 64, false, 0, 17)
       default: return -1;
     }

@@ -1,0 +1,351 @@
+// Lean 64x64 instance of the fp32 implicit-GEMM engine (gather_gemm.hip has the general one).
+//
+// Why a second kernel: on gfx950 the exact-f32 MFMA (v_mfma_f32_32x32x2_f32, 64 cycles) does NOT overlap
+// with other vector instructions of the same SIMD -- measured with tools/micro/mfma_issue.hip: every
+// VALU / LDS / VMEM instruction issued beside the MFMAs adds ~4 cycles to the MFMA time, with 1 or 7
+// waves per SIMD alike (profiles/r01_micro_mfma_issue.txt).  The K loop of the general kernel carries
+// ~30 such instructions per 8 MFMAs (512 cycles); this one carries 15 (forward, BatchNorm prologue) /
+// 10 (input gradient):
+//   * the gather address of a (row, tap) pair is  voffset | validity  +  an SGPR offset:  the per-row
+//     byte offset never changes, the tap / channel-slice displacement is wave-uniform and rides in the
+//     buffer instruction's scalar offset (excluded from the range check), and an invalid pair (padding
+//     pixel, row past M, chunk past K) ORs the sign-extended bit of an inverted tap mask into the
+//     offset, which sends it out of range: the load returns zeros.  2 VALU per A load, 0 per B load;
+//   * the producer BatchNorm is 4 v_fma: its shift is fetched through the same masked offset, so a
+//     padding pixel gets shift 0 and stays exactly 0 without a select;
+//   * chunk -> (tap, channel slice) is carried incrementally in SGPRs.
+// Constraints (else the general kernel runs): Cin % 16 == 0, operands < 2 GiB, <= 31 taps.
+// Same data layout, epilogues and results as gather_gemm_kernel (k order inside a chunk included).
+#include "gg_common.h"
+
+__device__ __forceinline__ float4 bload4s(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+  const v4f f = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+  return make_float4(f[0], f[1], f[2], f[3]);
+}
+
+template <bool MODE1, int AFF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void gather_gemm_v3_kernel(const GGParams p) {
+  constexpr int BM = 64, BN = 64, BK = 16;
+  constexpr int LDK = BK + 4;
+  constexpr int A_ELEMS = BM * LDK;
+  constexpr int LDN = BN + 4;
+  constexpr int B_ELEMS = MODE1 ? BN * LDK : BK * LDN;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * A_ELEMS;
+  unsigned* s_offb = reinterpret_cast<unsigned*>(Bs + 2 * B_ELEMS);   // [BM] output row byte offsets
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lh = lane >> 5, l31 = lane & 31;
+
+  int bnt, btile, kz;
+  veex_block_coords(p.remap, p.gx, p.gy, bnt, btile, kz);
+  int tile = btile, ph = 0;
+  if (p.nphase == 4) {
+    while (ph < 3 && tile >= p.tile_prefix[ph + 1]) ++ph;
+  }
+  const int py = ph >> 1, px = ph & 1;
+  const int Hp = p.Hp[py], Wp = p.Wp[px];
+  const int ostep = (p.nphase == 4) ? 2 : 1;
+  const int oy0 = p.o0[py], ox0 = p.o0[px];
+  const int Mph = p.Nb * Hp * Wp;
+  const int m0 = (tile - p.tile_prefix[ph]) * BM;
+  const int n0 = bnt * BN;
+
+  int kys = 0, kxs = 0, kstep = 1, nky = p.kh, nkx = p.kw;
+  if (p.nphase == 4) {
+    kys = py; kxs = px; kstep = 2;
+    nky = (p.kh - py + 1) >> 1;
+    nkx = (p.kw - px + 1) >> 1;
+  }
+  const int cpt = p.Cin / BK;
+  const int ntaps = nky * nkx;
+  const int nchunks = ntaps * cpt;
+  const int c_begin = kz * p.chunks_per_split;
+  const int c_end = min(nchunks, c_begin + p.chunks_per_split);
+  const int HWp = Hp * Wp;
+
+  if (tid < BM) {
+    const int m = m0 + tid;
+    unsigned off = 0x80000000u;   // + any column offset stays out of range: the store is dropped
+    if (m < Mph) {
+      const int n = m / HWp, rem = m - n * HWp;
+      const int j = rem / Wp, i = rem - j * Wp;
+      off = (unsigned)(((n * p.Hout + ostep * j + oy0) * p.Wout + ostep * i + ox0) * p.Cout) * 4u;
+    }
+    s_offb[tid] = off;
+  }
+
+  // Bias: the scalar offset of a tap must be >= 0, so the per-row offset is taken at the tap with the lowest
+  // address; for rows at the top-left border that pixel lies before the tensor, hence every per-row offset
+  // is shifted up by `bias` bytes and the resource base down by the same amount (never dereferenced there:
+  // such a (row, tap) pair is masked).
+  const int bias_pix = MODE1 ? ((nky - 1) * p.Win + (nkx - 1)) : p.pb * (p.Win + 1);
+  const int bias_bytes = bias_pix * p.Cin * 4;
+  const unsigned a_total = (unsigned)p.Nb * p.Hin * p.Win * p.Cin * 4u;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(p.A)) - bias_bytes, 0, (int)(a_total + (unsigned)bias_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.W), 0, (int)((unsigned)p.kh * p.kw * p.Cin * p.Cout * 4u), 0x00020000);
+  const unsigned aff_bytes = (AFF != 0) ? (unsigned)(p.aff_mask + 1) * 4u : 0u;
+  const int aff_bias = (AFF == 2) ? bias_bytes : 0;
+  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(AFF != 0 ? p.a_scale : p.A)) - aff_bias, 0, (int)(aff_bytes + (unsigned)aff_bias), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(AFF != 0 ? p.a_shift : p.A)) - aff_bias, 0, (int)(aff_bytes + (unsigned)aff_bias), 0x00020000);
+
+  // ---- A loader: row tid/4, k-quad tid%4 ----
+  const int q = tid & 3, lr = tid >> 2;
+  unsigned a_voff = 0u, a_voff2 = 0u, a_inv = 0xFFFFFFFFu;   // a_inv bit t set <=> tap t must read zeros
+  {
+    const int m = m0 + lr;
+    if (m < Mph) {
+      const int n = m / HWp, rem = m - n * HWp;
+      const int j = rem / Wp, ii = rem - j * Wp;
+      const int oy = ostep * j + oy0, ox = ostep * ii + ox0;
+      int by, bx;   // input pixel read by phase tap (0,0)
+      if (MODE1) { by = (oy + p.pb - kys) >> (p.stride - 1); bx = (ox + p.pb - kxs) >> (p.stride - 1); }
+      else       { by = p.stride * oy - p.pb; bx = p.stride * ox - p.pb; }
+      // lowest-address tap: MODE1 (by-(nky-1), bx-(nkx-1)), MODE0 (by, bx); plus the bias
+      const int nbase = n * p.Hin * p.Win * p.Cin * 4;
+      const int inner = ((MODE1 ? (by * p.Win + bx) : ((by + p.pb) * p.Win + bx + p.pb)) * p.Cin + 4 * q) * 4;
+      a_voff = (unsigned)(nbase + inner);
+      a_voff2 = (unsigned)inner;
+      unsigned mk = 0u;
+      for (int ia = 0; ia < nky; ++ia)
+        for (int ib = 0; ib < nkx; ++ib) {
+          const int iy = MODE1 ? by - ia : by + ia, ix = MODE1 ? bx - ib : bx + ib;
+          bool ok = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+          if (MODE1) ok = ok && (oy + p.pb - (kys + kstep * ia)) >= 0 && (ox + p.pb - (kxs + kstep * ib)) >= 0;
+          if (ok) mk |= 1u << (ia * nkx + ib);
+        }
+      a_inv = ~mk;   // bits >= ntaps (bit 31 included: "chunk past the end") stay set
+    }
+  }
+  // ---- B loader ----
+  unsigned b_voff;
+  if (MODE1) {   // [tap][Cout][Cin]: row n0 + tid/4, quad q along Cin
+    const int n = n0 + lr;
+    b_voff = (n < p.Cout) ? (unsigned)((n * p.Cin + 4 * q) * 4) : VEEX_OOB;
+  } else {       // [tap][Cin][Cout]: row tid/16, quad tid%16 along Cout
+    const int n = n0 + 4 * (tid & 15);
+    b_voff = (n < p.Cout) ? (unsigned)(((tid >> 4) * p.Cout + n) * 4) : VEEX_OOB;
+  }
+  const int tap_bytes = p.Cin * p.Cout * 4;
+  const unsigned s_voff = (unsigned)(16 * q);   // AFF == 1: this thread's 4 channels of the slice
+
+  struct Stage { float4 ra, rb, rsc, rsh; };
+
+  // running (tap, channel slice) of the next chunk to load; chunks are loaded strictly in order
+  int it_c = c_begin;
+  int it_cc = c_begin / ntaps;
+  int it_tapi = c_begin - it_cc * ntaps;
+  int it_ia = it_tapi / nkx, it_ib = it_tapi - it_ia * nkx;
+
+  auto load_chunk = [&](Stage& st) {
+    const bool cvalid = it_c < c_end;
+    const int tapi = cvalid ? it_tapi : 31;     // bit 31 of a_inv is always set: zeros
+    const int ia = it_ia, ib = it_ib;
+    const int ci0b = cvalid ? it_cc * (BK * 4) : 0;
+    const int tap = cvalid ? (kys + kstep * ia) * p.kw + (kxs + kstep * ib) : 0;
+    const int dpix = MODE1 ? ((nky - 1 - ia) * p.Win + (nkx - 1 - ib)) : (ia * p.Win + ib);
+    const int delta = cvalid ? dpix * p.Cin * 4 + ci0b : 0;
+    ++it_c; ++it_tapi; ++it_ib;
+    if (it_ib == nkx) { it_ib = 0; ++it_ia; }
+    if (it_tapi == ntaps) { it_tapi = 0; it_ia = 0; it_ib = 0; ++it_cc; }
+
+    const unsigned m = (unsigned)__builtin_amdgcn_sbfe(a_inv, tapi, 1);   // 0 or 0xFFFFFFFF
+    st.ra = bload4s(rA, a_voff | m, delta);
+    if (AFF == 1) {
+      st.rsc = bload4s(rS, s_voff, ci0b);
+      st.rsh = bload4s(rH, s_voff | m, ci0b);
+    } else if (AFF == 2) {
+      st.rsc = bload4s(rS, a_voff2 | m, delta);
+      st.rsh = bload4s(rH, a_voff2 | m, delta);
+    }
+    st.rb = bload4s(rW, b_voff, tap * tap_bytes + (MODE1 ? ci0b : ci0b * p.Cout));
+  };
+
+  auto store_chunk = [&](const Stage& st, int buf) {
+    float* as = As + buf * A_ELEMS;
+    float* bs = Bs + buf * B_ELEMS;
+    float4 v = st.ra;
+    if (AFF != 0) {   // padding pixels: value 0, shift 0 -> stay exactly 0
+      v.x = fmaf(v.x, st.rsc.x, st.rsh.x); v.y = fmaf(v.y, st.rsc.y, st.rsh.y);
+      v.z = fmaf(v.z, st.rsc.z, st.rsh.z); v.w = fmaf(v.w, st.rsc.w, st.rsh.w);
+    }
+    *reinterpret_cast<float4*>(as + lr * LDK + 4 * q) = v;
+    if (MODE1) *reinterpret_cast<float4*>(bs + lr * LDK + 4 * q) = st.rb;
+    else       *reinterpret_cast<float4*>(bs + (tid >> 4) * LDN + 4 * (tid & 15)) = st.rb;
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  // K order inside a chunk is permuted: lanes 0-31 feed k = 0..7, lanes 32-63 k = 8..15
+  auto compute = [&](int cur) {
+    const float* as = As + cur * A_ELEMS + (wm * 32 + l31) * LDK + 8 * lh;
+    const float* bs = MODE1 ? (Bs + cur * B_ELEMS + (wn * 32 + l31) * LDK + 8 * lh)
+                            : (Bs + cur * B_ELEMS + (8 * lh) * LDN + wn * 32 + l31);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float av[4], bv[4];
+      const float4 t = *reinterpret_cast<const float4*>(as + 4 * half);
+      av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
+      if (MODE1) {
+        const float4 u = *reinterpret_cast<const float4*>(bs + 4 * half);
+        bv[0] = u.x; bv[1] = u.y; bv[2] = u.z; bv[3] = u.w;
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) bv[kk] = bs[(4 * half + kk) * LDN];
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
+    }
+  };
+
+  // two chunks of global loads in flight, one barrier per chunk (see gather_gemm_kernel)
+  Stage s0, s1;
+  load_chunk(s0);
+  store_chunk(s0, 0);
+  load_chunk(s0);
+  __syncthreads();
+  for (int c = c_begin; c < c_end; c += 2) {
+    load_chunk(s1);
+    compute(0);
+    store_chunk(s0, 1);
+    __syncthreads();
+    load_chunk(s0);
+    compute(1);
+    store_chunk(s1, 0);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+  const int col = n0 + wn * 32 + l31;
+  const bool colok = col < p.Cout;
+  float* outp = p.Out;
+  if (p.epi == VEEX_EPI_RAW) outp += (long long)kz * p.slab_stride;
+  const unsigned out_bytes = (unsigned)p.Nb * p.Hout * p.Wout * p.Cout * 4u;
+  const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc(outp, 0, (int)out_bytes, 0x00020000);
+  const unsigned col4 = (unsigned)col * 4u;
+  float cs1 = 0.f, cs2 = 0.f, cs3 = 0.f;
+  if (colok) {
+    if (p.epi == VEEX_EPI_FWD) {
+      const float bia = (p.bias != nullptr) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const uint4 ro = *reinterpret_cast<const uint4*>(s_offb + wm * 32 + 8 * g + 4 * lh);
+        const unsigned rof[4] = {ro.x, ro.y, ro.z, ro.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[4 * g + e] + bia;
+          if (p.relu) v = fmaxf(v, 0.f);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rO, rof[e] + col4, 0, 0);
+        }
+      }
+    } else if (p.epi == VEEX_EPI_BWD) {
+      const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.aux), 0, (int)out_bytes, 0x00020000);
+      const float esc = (p.e_scale != nullptr) ? p.e_scale[col & p.epi_cmask] : 1.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const uint4 ro = *reinterpret_cast<const uint4*>(s_offb + wm * 32 + 8 * g + 4 * lh);
+        const unsigned rof[4] = {ro.x, ro.y, ro.z, ro.w};
+        float a[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)   // rows past M: out of range -> 0 (and their accumulators are 0)
+          a[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rX, rof[e] + col4, 0, 0));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = acc[4 * g + e];
+          const float vm = (!p.relu || a[e] > 0.f) ? v : 0.f;
+          cs1 += v;
+          cs2 = fmaf(v, a[e], cs2);
+          cs3 += vm;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vm * esc), rO, rof[e] + col4, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const uint4 ro = *reinterpret_cast<const uint4*>(s_offb + wm * 32 + 8 * g + 4 * lh);
+        const unsigned rof[4] = {ro.x, ro.y, ro.z, ro.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = acc[4 * g + e];   // (bit-casting the vector element in place stored acc[0] sixteen times)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rO, rof[e] + col4, 0, 0);
+        }
+      }
+    }
+  }
+
+  if (p.epi == VEEX_EPI_BWD && p.partials != nullptr) {
+    // column sums: lane halves -> the two waves sharing the columns -> one row of the partial slab
+    float* s_red = As;   // [2][BN][3]; safe: every wave passed the loop's last barrier
+    cs1 += __shfl_xor(cs1, 32);
+    cs2 += __shfl_xor(cs2, 32);
+    cs3 += __shfl_xor(cs3, 32);
+    if (lh == 0) {
+      const int cl = wn * 32 + l31;
+      s_red[(wm * BN + cl) * 3 + 0] = cs1;
+      s_red[(wm * BN + cl) * 3 + 1] = cs2;
+      s_red[(wm * BN + cl) * 3 + 2] = cs3;
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.Cout) {
+      const float t1 = s_red[tid * 3 + 0] + s_red[(BN + tid) * 3 + 0];
+      const float t2 = s_red[tid * 3 + 1] + s_red[(BN + tid) * 3 + 1];
+      const float t3 = s_red[tid * 3 + 2] + s_red[(BN + tid) * 3 + 2];
+      float* pp = p.partials + (long long)btile * 3 * p.Cout + n0 + tid;
+      pp[0] = t1;
+      pp[p.Cout] = t2;
+      pp[2 * p.Cout] = t3;
+    }
+  }
+}
+
+template <bool MODE1>
+static void gg3_launch(const GGParams& p, int aff, dim3 grid, hipStream_t st) {
+  constexpr size_t lds = (2 * 64 * 20 + 2 * (MODE1 ? 64 * 20 : 16 * 68)) * sizeof(float) + 64 * sizeof(unsigned);
+  if (aff == 0) hipLaunchKernelGGL((gather_gemm_v3_kernel<MODE1, 0>), grid, dim3(256), lds, st, p);
+  else if (aff == 1) hipLaunchKernelGGL((gather_gemm_v3_kernel<MODE1, 1>), grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((gather_gemm_v3_kernel<MODE1, 2>), grid, dim3(256), lds, st, p);
+}
+
+// 1: the lean kernel can run this launch (64-row tiles already chosen by the caller)
+int veex_gg_v3_ok(const GGParams& p) {
+  const long long a_bytes = (long long)p.Nb * p.Hin * p.Win * p.Cin * 4;
+  const long long bias = ((long long)(p.kh - 1) * p.Win + p.kw + (long long)p.pb * (p.Win + 1)) * p.Cin * 4;
+  const long long o_bytes = (long long)p.Nb * p.Hout * p.Wout * p.Cout * 4;
+  const long long w_bytes = (long long)p.kh * p.kw * p.Cin * p.Cout * 4;
+  if (p.Cin % 16 != 0 || p.kh * p.kw > 31) return 0;
+  if (p.mode == 0 && p.Cout % 4 != 0) return 0;
+  if (a_bytes + bias >= 0x7FFF0000LL || o_bytes >= 0x7FFF0000LL || w_bytes >= 0x7FFF0000LL) return 0;
+  if (p.OutBf != nullptr || p.Abf != nullptr) return 0;
+  if (p.a_scale != nullptr && p.aff_spatial && (p.aff_mask + 1) != p.Hin * p.Win * p.Cin) return 0;
+  if (p.a_scale != nullptr && !p.aff_spatial && (p.aff_mask + 1) < p.Cin) return 0;
+  if (p.epi == VEEX_EPI_BWD && p.e_scale != nullptr && p.epi_cmask + 1 < 1) return 0;
+  return 1;
+}
+
+// p: validated by veex_launch_gather_gemm, phase tables filled for 64-row tiles
+int veex_launch_gather_gemm_v3(GGParams& p, int mtiles, hipStream_t st) {
+  const int ntiles = (p.Cout + 63) / 64;
+  if (p.nsplit > 1) {
+    const int nchunks = p.kh * p.kw * (p.Cin / 16);
+    p.chunks_per_split = (nchunks + p.nsplit - 1) / p.nsplit;
+  }
+  const int xr = veex_env_int("VEEX_XCD", -1);
+  p.remap = (xr < 0) ? (p.nphase == 1) : xr;
+  p.gx = ntiles; p.gy = mtiles; p.gz = p.nsplit;
+  dim3 grid((unsigned)ntiles * mtiles * p.nsplit, 1, 1);
+  const int aff = (p.a_scale == nullptr) ? 0 : (p.aff_spatial ? 2 : 1);
+  if (p.mode == 1) gg3_launch<true>(p, aff, grid, st);
+  else gg3_launch<false>(p, aff, grid, st);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
