@@ -113,6 +113,9 @@ typedef struct VeexWgradDesc {
   const void* small_bf16;  /* activation side): both given + bf16=1 -> copy kernel (rows_per_split % 64 == 0) */
 } VeexWgradDesc;
 int veex_wgrad_gemm(const VeexWgradDesc* d, veexStream_t stream);
+/* The row split veex_net_train_fwd_bwd would use for this launch (fills nsplit / rows_per_split from the
+ * geometry and d->bf16; the caller sizes `out` as nsplit * kh*kw*Cb * Cs floats).  Host only. */
+int veex_wgrad_plan(const VeexWgradDesc* d, int32_t* nsplit, int32_t* rows_per_split);
 
 /* conv1 of the encoder, Conv2D(64,3,strides=2,'same',relu) on the 40x40x1 map (models.py:219-221). */
 int veex_conv1_fwd(const float* x, const float* w, const float* bias, float* out, int batch, veexStream_t s);

@@ -26,7 +26,7 @@ def per_dispatch(path):
     d = collections.OrderedDict()
     for r in csv.DictReader(open(path)):
         d.setdefault((int(r["Dispatch_Id"]), r["Kernel_Name"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
-    return [(k, v) for k, v in d.items() if "gather_gemm_kernel" in k[1] or "wgrad_kernel" in k[1]]
+    return [(k, v) for k, v in d.items() if "gather_gemm" in k[1] or "wgrad_" in k[1]]
 
 
 order = open(f"{src}/pmc_fetch.log").read().split("launch order:")[1].split()[0].split(",")

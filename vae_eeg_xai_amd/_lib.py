@@ -65,6 +65,7 @@ SIGNATURES = {
     "veex_net_set_compute": (_I, [_P, _I]),
     "veex_net_set_side_stream": (_I, [_P, _P]),
     "veex_wgrad_gemm": (_I, [C.POINTER(WgradDesc), _P]),
+    "veex_wgrad_plan": (_I, [C.POINTER(WgradDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "veex_conv1_fwd": (_I, [_P, _P, _P, _P, _I, _P]),
     "veex_conv1_fwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "veex_conv1_wgrad_blocks": (_I, [_I]),

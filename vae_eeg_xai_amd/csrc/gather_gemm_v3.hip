@@ -8,7 +8,7 @@
 // 10 (input gradient):
 //   * the gather address of a (row, tap) pair is  voffset | validity  +  an SGPR offset:  the per-row
 //     byte offset never changes, the tap / channel-slice displacement is wave-uniform and rides in the
-//     buffer instruction's scalar offset (excluded from the range check), and an invalid pair (padding
+//     buffer instruction's scalar offset (gfx950 range-checks voffset + soffset), and an invalid pair (padding
 //     pixel, row past M, chunk past K) ORs the sign-extended bit of an inverted tap mask into the
 //     offset, which sends it out of range: the load returns zeros.  2 VALU per A load, 0 per B load;
 //   * the producer BatchNorm is 4 v_fma: its shift is fetched through the same masked offset, so a

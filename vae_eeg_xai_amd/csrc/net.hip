@@ -324,14 +324,31 @@ static SplitPlan wgrad_split(const WGParams& pin) {
   const int tiles = veex_wg_tiles(pin, &bm, &bn);
   const int bk = (pin.bf16 == 2) ? 64 : pin.bf16 ? 32 : VEEX_BK;   // reduction rows per K chunk of the kernel that will run
   const int chunks = (pin.R + bk - 1) / bk;
-  const int target = veex_env_int("VEEX_WG_BLOCKS", 768);   // blocks per launch the row split aims at
-  int ns = (target + tiles - 1) / tiles;
+  // Blocks per launch the row split aims at: 3 per CU, all resident at once and equally long, so the launch
+  // lasts as long as the fullest CU -- never exceed the target (774 blocks = a 4th block on six CUs = +33 %).
+  const int target = veex_env_int("VEEX_WG_BLOCKS", 768);
+  int ns = veex_env_int("VEEX_WG_FLOOR", 1) ? target / tiles : (target + tiles - 1) / tiles;
   const int maxs = (chunks / 4 > 0) ? chunks / 4 : 1;
   if (ns > maxs) ns = maxs;
   if (ns < 1) ns = 1;
   const int cps = (chunks + ns - 1) / ns;
-  SplitPlan s; s.per = cps * bk; s.nsplit = (pin.R + s.per - 1) / s.per;
+  SplitPlan s; s.per = cps * bk;
+  if (!pin.bf16 && s.per > VEEX_WG3_MAX_ROWS) s.per = VEEX_WG3_MAX_ROWS;   // keep the lean kernel's row table in LDS
+  s.nsplit = (pin.R + s.per - 1) / s.per;
   return s;
+}
+
+extern "C" int veex_wgrad_plan(const VeexWgradDesc* d, int32_t* nsplit, int32_t* rows_per_split) {
+  if (d == nullptr || nsplit == nullptr || rows_per_split == nullptr) { veex_set_error("wgrad_plan: null argument"); return VEEX_EINVAL; }
+  WGParams p; memset(&p, 0, sizeof(p));
+  p.Nb = d->N; p.Hb = d->Hb; p.Wb = d->Wb; p.Cb = d->Cb; p.Hs = d->Hs; p.Ws = d->Ws; p.Cs = d->Cs;
+  p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pb = d->pad_begin;
+  p.R = p.Nb * p.Hs * p.Ws; p.M = p.kh * p.kw * p.Cb;
+  p.bf16 = d->bf16 ? ((d->big_bf16 != nullptr && d->small_bf16 != nullptr) ? 2 : 1) : 0;
+  if (p.R < 1 || p.M < 1 || p.Cs < 1) { veex_set_error("wgrad_plan: bad geometry"); return VEEX_EINVAL; }
+  const SplitPlan s = wgrad_split(p);
+  *nsplit = s.nsplit; *rows_per_split = s.per;
+  return 0;
 }
 
 static int gg_split(int mtiles, int Cout, int chunks) {

@@ -104,6 +104,9 @@ int veex_gg_m_tiles_bm(GGParams& p, int bm);   // same for a given tile height (
 int veex_gg_bm(const GGParams& p);
 int veex_wg_tiles(const WGParams& p, int* bm, int* bn);
 int veex_wgrad_bf16_ok(const WGParams& p);                       // wgrad_gemm_bf16.hip
+#define VEEX_WG3_MAX_ROWS 3072                                    // rows_per_split the LDS row table of wgrad_gemm_v3.hip holds
+int veex_wgrad_v3_ok(const WGParams& p);                         // wgrad_gemm_v3.hip
+int veex_launch_wgrad_v3(const WGParams& p, int bm, int bn, hipStream_t st);
 int veex_launch_wgrad_bf16(const WGParams& p, hipStream_t st);
 extern "C" int veex_conv1_fwd_bf16(const float* x, const float* W, const float* bias, float* out, const float* bn_scale,
                                    const float* bn_shift, void* out_bf16, int B, hipStream_t st);

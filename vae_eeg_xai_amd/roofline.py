@@ -124,21 +124,16 @@ def gemm_cases(B, bf16=False):
         d.N, d.Hb, d.Wb, d.Cb, d.Hs, d.Ws, d.Cs = N, Hb, Hb, Cb, Hs, Hs, Cs
         d.kh = d.kw = k
         d.stride, d.pad_begin = stride, pb
-        R = N * Hs * Hs
         M = k * k * Cb
-        tiles = ((M + 127) // 128) * ((Cs + 127) // 128 if Cs > 64 else 1)
-        bk = 64 if bf16 else 16
         d.bf16 = 1 if bf16 else 0
         if bf16:
             bb = (big * aff_big[0] + aff_big[1]) if aff_big is not None else big
             sb = (small * aff_small[0] + aff_small[1]) if aff_small is not None else small
             bb, sb = bb.to(torch.bfloat16), sb.to(torch.bfloat16)
             keep.extend([bb, sb]); d.big_bf16, d.small_bf16 = bb.data_ptr(), sb.data_ptr()
-        chunks = (R + bk - 1) // bk
-        ns = max(1, min((768 + tiles - 1) // tiles, max(chunks // 4, 1)))
-        cps = (chunks + ns - 1) // ns
-        d.rows_per_split = cps * bk
-        d.nsplit = (R + d.rows_per_split - 1) // d.rows_per_split
+        ns, per = C.c_int32(), C.c_int32()   # the row split the whole-step entry point uses
+        check(lib.veex_wgrad_plan(C.byref(d), C.byref(ns), C.byref(per)), "wgrad_plan")
+        d.nsplit, d.rows_per_split = ns.value, per.value
         out = torch.empty(d.nsplit * M * Cs, device="cuda")
         d.out = out.data_ptr()
         keep.extend([big, small, out, d])
@@ -221,7 +216,7 @@ def dominant_kernel_roofline(net, batch):
         traffic = _pmc_traffic("dec.deconv4.fwd")
         if bf16:
             traffic = None   # PMC passes of the bf16 kernels: profiles/*_pmc_gemms_bf16.json when collected
-        best = {"bound": "mfma", "kernel": ("gather_gemm_bf16_kernel" if bf16 else "gather_gemm_kernel") +
+        best = {"bound": "mfma", "kernel": ("gather_gemm_bf16_kernel" if bf16 else "gather_gemm_v3_kernel") +
                 " mode 1 (dec.deconv4 forward, Conv2DTranspose 128->64 k3 s1)",
                 "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                 "traffic": traffic, "traffic_source": _PMC_NOTE if traffic is not None else None, "us_per_launch": t * 1e6, "algorithmic_flop_per_launch": 2.0 * macs}
