@@ -471,23 +471,26 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
   }
 }
 
-// Same result for "many slabs, few elements": 64 columns x 16 slab lanes per block; every lane sums
-// its slabs in increasing order, then the 16 lane sums are added in lane order (fixed order -> reproducible).
-__global__ __launch_bounds__(1024) void slab_sum_tall_kernel(const float* __restrict__ slab, int nsplit,
+// Same result for "many slabs, few elements": 64 columns x LY slab lanes per block; every lane sums
+// its slabs in increasing order, then the LY lane sums are added in lane order (fixed order -> reproducible).
+// LY = 16 for the few-column case; LY = 4 (256-thread blocks, which find a free slot beside a GEMM of the
+// other stream far sooner than a 1024-thread block) otherwise.
+template <int LY>
+__global__ __launch_bounds__(64 * LY) void slab_sum_tall_kernel(const float* __restrict__ slab, int nsplit,
                                                              long long stride, long long n, float* __restrict__ out,
                                                              const float* __restrict__ bias, int ncols, int relu) {
-  __shared__ float red[16][64];
+  __shared__ float red[LY][64];
   const int cx = threadIdx.x & 63, ly = threadIdx.x >> 6;
   const long long i = (long long)blockIdx.x * 64 + cx;
   float s = 0.f;
   if (i < n)
-    for (int k = ly; k < nsplit; k += 16) s += slab[(long long)k * stride + i];
+    for (int k = ly; k < nsplit; k += LY) s += slab[(long long)k * stride + i];
   red[ly][cx] = s;
   __syncthreads();
   if (ly == 0 && i < n) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[k][cx];
+    for (int k = 0; k < LY; ++k) t += red[k][cx];
     if (bias != nullptr) t += bias[(int)(i % ncols)];
     if (relu) t = fmaxf(t, 0.f);
     out[i] = t;
@@ -693,8 +696,11 @@ int veex_colsum_finalize(const float* partials, int T, long long row_stride, int
 
 int veex_slab_sum(const float* slab, int nsplit, long long stride, long long n, float* out, const float* bias,
                    int ncols, int relu, hipStream_t st) {
-  if (nsplit > 32 && n <= 65536)
-    hipLaunchKernelGGL(slab_sum_tall_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, st, slab, nsplit, stride, n,
+  if (nsplit > 32 && n <= 4096)
+    hipLaunchKernelGGL(slab_sum_tall_kernel<16>, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, st, slab, nsplit, stride, n,
+                       out, bias, ncols, relu);
+  else if (nsplit > 32 && n <= 65536)
+    hipLaunchKernelGGL(slab_sum_tall_kernel<4>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, slab, nsplit, stride, n,
                        out, bias, ncols, relu);
   else
     hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, slab, nsplit, stride, n, out,

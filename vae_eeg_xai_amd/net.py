@@ -8,6 +8,7 @@ torch.distributed); every arithmetic op of the hot path runs in the HIP library.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Iterable, List, Optional, Sequence
 
 import numpy as np
@@ -103,7 +104,7 @@ class Net:
         with the input-gradient chain (joined before train_fwd_bwd returns)."""
         if on and self._side_stream is None:
             with torch.cuda.device(self.device):
-                self._side_stream = torch.cuda.Stream(device=self.device)
+                self._side_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("VEEX_SIDE_PRIO", "0")))
         s = self._side_stream.cuda_stream if on else None
         check(lib.veex_net_set_side_stream(self._h, C.c_void_p(s) if s is not None else None), "net_set_side_stream")
         self.overlap = bool(on)
