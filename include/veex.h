@@ -182,6 +182,21 @@ int veex_denormalize(const float* x, const float* minmax, float* out, long long 
 int veex_electrode_readout(const float* maps, const int* pix, const float* minmax, float* out, int batch,
                            int map_elems, int n_electrodes, veexStream_t s);
 
+/* Latent statistics, the step right after the path in analysis.py.  z: DEVICE [N][L] fp32
+ * (z_mean as the encoder wrote it), one column per latent unit.
+ * veex_column_quantiles: np.quantile(z, q, axis=0) as NumPy 1.24 (the reference's pin) computes it for a
+ *   float32 array and Python-float orders -- 'linear' method, fp32 neighbour difference, float64 weight and
+ *   result (analysis.py:243-244,298).  q: HOST array of nq <= 24 orders in [0,1]; out: DEVICE [nq][L] float64;
+ *   scratch: DEVICE, veex_column_quantiles_scratch_bytes(nq, L) bytes.  Exact order statistics by radix select.
+ * veex_band_outside_counts: counts[j*nb + k] = #{i : z[i][j] <= lo[j*nb+k] or z[i][j] >= hi[j*nb+k]} with
+ *   float64 compares -- the TP (blink rows) / FP (no-blink rows) counters of histogram_25_75 and auc_roc
+ *   (analysis.py:255-264,323-333); FN / TN are N minus these.  lo, hi: DEVICE [L][nb] float64. */
+long long veex_column_quantiles_scratch_bytes(int nq, int L);
+int veex_column_quantiles(const float* z, int N, int L, const double* q, int nq, double* out, void* scratch,
+                          veexStream_t s);
+int veex_band_outside_counts(const float* z, int N, int L, int nb, const double* lo, const double* hi, int* counts,
+                             veexStream_t s);
+
 /* ------------------------------------------------------------------------------------------
  * Network level: the whole Encoder / Decoder / VAE.train_step graph as one enqueue.
  * ---------------------------------------------------------------------------------------- */

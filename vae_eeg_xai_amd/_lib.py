@@ -87,6 +87,9 @@ SIGNATURES = {
     "veex_normalize": (_I, [_P, _P, _P, _L, _P]),
     "veex_denormalize": (_I, [_P, _P, _P, _L, _P]),
     "veex_electrode_readout": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "veex_column_quantiles_scratch_bytes": (_L, [_I, _I]),
+    "veex_column_quantiles": (_I, [_P, _I, _I, C.POINTER(_D), _I, _P, _P, _P]),
+    "veex_band_outside_counts": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
     "veex_net_create": (_P, [_I, _I]),
     "veex_net_destroy": (None, [_P]),
     "veex_net_param_floats": (_L, [_P]),
