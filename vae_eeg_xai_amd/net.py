@@ -101,10 +101,12 @@ class Net:
 
     def set_overlap(self, on: bool):
         """Run the weight-gradient GEMMs of the backward pass on a second HIP stream, concurrently
-        with the input-gradient chain (joined before train_fwd_bwd returns)."""
+        with the input-gradient chain (joined before train_fwd_bwd returns).  VEEX_OVERLAP=0 forces one stream
+        (profiling: kernel durations then are stand-alone)."""
+        on = bool(on) and os.environ.get("VEEX_OVERLAP", "1") != "0"
         if on and self._side_stream is None:
             with torch.cuda.device(self.device):
-                self._side_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("VEEX_SIDE_PRIO", "0")))
+                self._side_stream = torch.cuda.Stream(device=self.device, priority=0)
         s = self._side_stream.cuda_stream if on else None
         check(lib.veex_net_set_side_stream(self._h, C.c_void_p(s) if s is not None else None), "net_set_side_stream")
         self.overlap = bool(on)
