@@ -168,6 +168,19 @@ __global__ __launch_bounds__(256) void conv1_dgrad_kernel(const float* __restric
 // phase 2: per output pixel gather <=4 of them, BCE, dlogit = (sigmoid - t)/B, block reduction.
 // ---------------------------------------------------------------------------------------
 #define D6_THREADS 512
+// sum over the 16 lanes of a DPP row with four v_add_f32 ... dpp (quad xor 1, quad xor 2, half-row mirror, row
+// mirror) instead of four ds_bpermute round trips through the LDS pipe; every lane of the row gets the total
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);   // row_half_mirror
+  v = dpp_add<0x140>(v);   // row_mirror
+  return v;
+}
 __global__ __launch_bounds__(D6_THREADS) void deconv6_bce_fwd_kernel(
     const float* __restrict__ a5, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ W6, const float* __restrict__ b6, const float* __restrict__ target,
@@ -202,10 +215,7 @@ __global__ __launch_bounds__(D6_THREADS) void deconv6_bce_fwd_kernel(
       }
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      s[t] += __shfl_xor(s[t], 8); s[t] += __shfl_xor(s[t], 4);
-      s[t] += __shfl_xor(s[t], 2); s[t] += __shfl_xor(s[t], 1);
-    }
+    for (int t = 0; t < 4; ++t) s[t] = row16_sum(s[t]);
     if (cq == 0 && pix < D5H * D5H) *reinterpret_cast<float4*>(d + pix * 4) = make_float4(s[0], s[1], s[2], s[3]);
   }
   __syncthreads();

@@ -10,8 +10,8 @@
 // nothing per B load (constant per-thread offset + a wave-uniform SGPR offset; gfx950 range-checks
 // voffset + soffset, tools/micro/soffset_check.hip).  Rows past the split get an all-invalid mask, so
 // the A side is zero there and whatever the B side reads is multiplied away.
-// Constraints (else the general kernel): Cb % 4 == 0, Cs % 4 == 0, operands < 2 GiB, <= 31 taps, no
-// flattened (spatial) BatchNorm on the small operand, rows_per_split <= VEEX_WG3_MAX_ROWS.
+// Constraints (else the general kernel): Cb % 4 == 0, Cs % 4 == 0, operands < 2 GiB, <= 31 taps,
+// rows_per_split <= VEEX_WG3_MAX_ROWS.
 #include "veex_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -23,7 +23,8 @@ __device__ __forceinline__ float4 w3load(__amdgpu_buffer_rsrc_t r, unsigned voff
   return make_float4(f[0], f[1], f[2], f[3]);
 }
 
-template <int BM, int BN, bool AFFB, bool AFFS>
+// AFFS: 0 none, 1 per-channel BatchNorm on `small`, 2 BatchNorm over the flattened (h,w,c) vector of `small`
+template <int BM, int BN, bool AFFB, int AFFS>
 __global__ __launch_bounds__(256) void wgrad_v3_kernel(const WGParams p) {
   constexpr int BK = VEEX_BK;
   constexpr int WTM = BM / 2, WTN = BN / 2;
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(256) void wgrad_v3_kernel(const WGParams p) {
   float* As = smem;
   float* Bs = smem + 2 * A_ELEMS;
   int2* tab = reinterpret_cast<int2*>(Bs + 2 * B_ELEMS);   // [nchunks * BK] (row byte offset, inverted tap mask)
+  int* tabS = reinterpret_cast<int*>(tab + ((p.rows_per_split + BK - 1) / BK) * BK);   // AFFS == 2: byte offset of the row's pixel in the affine
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -73,6 +75,7 @@ __global__ __launch_bounds__(256) void wgrad_v3_kernel(const WGParams p) {
         inv = ~mk;
       }
       tab[t] = make_int2(off, (int)inv);
+      if (AFFS == 2) tabS[t] = (r % HWs) * p.Cs * 4;
     }
   }
 
@@ -103,12 +106,18 @@ __global__ __launch_bounds__(256) void wgrad_v3_kernel(const WGParams p) {
     bsh = *reinterpret_cast<const float4*>(p.b_shift + (acb & p.b_aff_mask));
   }
   float4 ssc = make_float4(1.f, 1.f, 1.f, 1.f), ssh = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (AFFS && bn_ok) {
+  if (AFFS == 1 && bn_ok) {
     ssc = *reinterpret_cast<const float4*>(p.s_scale + (bn & p.s_aff_mask));
     ssh = *reinterpret_cast<const float4*>(p.s_shift + (bn & p.s_aff_mask));
   }
+  const unsigned saff_bytes = (AFFS == 2) ? (unsigned)(p.s_aff_mask + 1) * 4u : 0u;
+  const __amdgpu_buffer_rsrc_t rSS = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(AFFS == 2 ? p.s_scale : p.Small), 0, (int)saff_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rSH = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(AFFS == 2 ? p.s_shift : p.Small), 0, (int)saff_bytes, 0x00020000);
+  const unsigned bn4 = bn_ok ? (unsigned)(bn * 4) : WG3_OOB;
 
-  float4 ra[APASS], rb[BPASS];
+  float4 ra[APASS], rb[BPASS], rssc[AFFS == 2 ? BPASS : 1], rssh[AFFS == 2 ? BPASS : 1];
   unsigned akeep[APASS];   // AFFB: all ones where the pixel is real (the BatchNorm shift applies), else 0
 
   auto load_chunk = [&](int c) {
@@ -122,7 +131,14 @@ __global__ __launch_bounds__(256) void wgrad_v3_kernel(const WGParams p) {
     }
     const int soff = (r_begin + c * BK) * p.Cs * 4;
 #pragma unroll
-    for (int i = 0; i < BPASS; ++i) rb[i] = w3load(rSmall, b_voff[i], soff);
+    for (int i = 0; i < BPASS; ++i) {
+      rb[i] = w3load(rSmall, b_voff[i], soff);
+      if (AFFS == 2) {
+        const unsigned ao = (unsigned)tabS[c * BK + brow + RPB * i] + bn4;
+        rssc[i] = w3load(rSS, ao, 0);
+        rssh[i] = w3load(rSH, ao, 0);
+      }
+    }
   };
 
   auto store_chunk = [&](int buf) {
@@ -142,9 +158,10 @@ __global__ __launch_bounds__(256) void wgrad_v3_kernel(const WGParams p) {
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
       float4 v = rb[i];
-      if (AFFS) {   // rows past the split / the tensor: the A side is 0 there, any finite value will do
-        v.x = fmaf(v.x, ssc.x, ssh.x); v.y = fmaf(v.y, ssc.y, ssh.y);
-        v.z = fmaf(v.z, ssc.z, ssh.z); v.w = fmaf(v.w, ssc.w, ssh.w);
+      if (AFFS != 0) {   // rows past the split / the tensor: the A side is 0 there, any finite value will do
+        const float4 sc = (AFFS == 2) ? rssc[AFFS == 2 ? i : 0] : ssc, sh = (AFFS == 2) ? rssh[AFFS == 2 ? i : 0] : ssh;
+        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+        v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
       }
       *reinterpret_cast<float4*>(bs + (brow + RPB * i) * LDB + 4 * bnq) = v;
     }
@@ -213,11 +230,13 @@ static int wg3_launch(const WGParams& pin, hipStream_t st) {
   p.remap = veex_env_int("VEEX_XCD_WG", 1);
   dim3 grid((unsigned)p.gx * p.gy * p.gz, 1, 1);
   const int tab_rows = (p.rows_per_split + VEEX_BK - 1) / VEEX_BK * VEEX_BK;
-  const size_t lds = 2 * VEEX_BK * ((BM + 4) + (BN + 4)) * sizeof(float) + (size_t)tab_rows * sizeof(int2);
-  const bool affb = p.b_scale != nullptr, affs = p.s_scale != nullptr;
-  if (!affb && !affs) hipLaunchKernelGGL((wgrad_v3_kernel<BM, BN, false, false>), grid, dim3(256), lds, st, p);
-  else if (!affb && affs) hipLaunchKernelGGL((wgrad_v3_kernel<BM, BN, false, true>), grid, dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((wgrad_v3_kernel<BM, BN, true, false>), grid, dim3(256), lds, st, p);
+  const bool affb = p.b_scale != nullptr;
+  const int affs = (p.s_scale == nullptr) ? 0 : (p.s_aff_spatial ? 2 : 1);
+  const size_t lds = 2 * VEEX_BK * ((BM + 4) + (BN + 4)) * sizeof(float) + (size_t)tab_rows * (sizeof(int2) + (affs == 2 ? sizeof(int) : 0));
+  if (!affb && affs == 0) hipLaunchKernelGGL((wgrad_v3_kernel<BM, BN, false, 0>), grid, dim3(256), lds, st, p);
+  else if (!affb && affs == 1) hipLaunchKernelGGL((wgrad_v3_kernel<BM, BN, false, 1>), grid, dim3(256), lds, st, p);
+  else if (!affb && affs == 2) hipLaunchKernelGGL((wgrad_v3_kernel<BM, BN, false, 2>), grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((wgrad_v3_kernel<BM, BN, true, 0>), grid, dim3(256), lds, st, p);
   VEEX_CHECK_LAUNCH();
   return 0;
 }
@@ -227,7 +246,7 @@ int veex_wgrad_v3_ok(const WGParams& p) {
   if (p.Cb % 4 != 0 || p.Cs % 4 != 0 || p.kh * p.kw > 31) return 0;
   if (big_bytes >= 0x7FFF0000LL || small_bytes >= 0x7FFF0000LL) return 0;
   if (p.b_scale != nullptr && (p.s_scale != nullptr || p.b_aff_spatial)) return 0;
-  if (p.s_scale != nullptr && p.s_aff_spatial) return 0;
+  if (p.s_scale != nullptr && p.s_aff_spatial && (p.s_aff_mask + 1) != p.Hs * p.Ws * p.Cs) return 0;
   if (p.rows_per_split > VEEX_WG3_MAX_ROWS) return 0;
   return 1;
 }
