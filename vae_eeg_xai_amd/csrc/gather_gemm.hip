@@ -698,7 +698,7 @@ int veex_launch_gather_gemm(const GGParams& pin, hipStream_t st) {
   const bool vec_ok = (p.Cin % 4 == 0) && (p.mode == 1 || p.Cout % 4 == 0);
   const bool fast = vec_ok && a_bytes < 0x7FFF0000LL && w_bytes < 0x7FFF0000LL && p.kh * p.kw <= 32 &&
                     (p.a_scale == nullptr || !p.aff_spatial || (p.aff_mask + 1) == p.Hin * p.Win * p.Cin);
-  if (p.Wbf != nullptr && fast && Mtot >= 4096 && Mtot < (1LL << 24) && p.Cin % 32 == 0) return veex_launch_gather_gemm_bf16(p, mtiles, st);
+  if (p.Wbf != nullptr && fast && Mtot >= 4096 && Mtot < (1LL << 24) && Mtot * p.Cout * 4 < 0x7FFF0000LL && p.Cin % 32 == 0) return veex_launch_gather_gemm_bf16(p, mtiles, st);
   if (bm == 64 && fast && veex_env_int("VEEX_GGV3", 1) && veex_gg_v3_ok(p)) return veex_launch_gather_gemm_v3(p, mtiles, st);
   if (bm == 128 && bn == 128 && fast) return gg_launch_cfg<128, 128>(p, mtiles, true, st);
   if (bm == 128 && bn == 64 && fast) return gg_launch_cfg<128, 64>(p, mtiles, true, st);

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GGParams p)
       fdivmod24(rem, Wp, invWp, j, i);
       off = (n * p.Hout + ostep * j + oy0) * p.Wout + ostep * i + ox0;
     }
-    s_off[tid] = off;
+    s_off[tid] = (off < 0) ? (int)0x80000000 : off * p.Cout * 4;   // byte offset of the fp32 output row (gg_epilogue_b)
   }
 
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GGParams p)
     if (t == 1.2345f) p.Out[tid] = t;   // keeps the accumulators alive
     return;
   }
-  gg_epilogue<BM, BN, WM, WN>(p, acc, s_off, reinterpret_cast<float*>(As), btile, kz, n0);
+  gg_epilogue_b<BM, BN, WM, WN>(p, acc, reinterpret_cast<const unsigned*>(s_off), reinterpret_cast<float*>(As), btile, kz, n0);
 }
 
 // ---------------------------------------------------------------------------
@@ -284,6 +284,41 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __r
     const int c = (int)(rem / R), r = (int)(rem - (long long)c * R);     // dst index = (t, c, r)
     dst[i] = (__bf16)src[t * per + (long long)r * C + c];
   }
+}
+
+// all packed copies of one step in ONE launch (14 tiny launches cost ~4.4 us each on the critical path)
+struct PackJob { const float* src; __bf16* dst; int taps, R, C, transpose, block0, blocks; };
+struct PackJobs { int n; PackJob j[16]; };
+__global__ __launch_bounds__(256) void pack_weights_bf16_multi_kernel(const PackJobs jobs) {
+  int k = 0;
+  while (k + 1 < jobs.n && (int)blockIdx.x >= jobs.j[k + 1].block0) ++k;
+  const PackJob J = jobs.j[k];
+  const long long n = (long long)J.taps * J.R * J.C, per = (long long)J.R * J.C;
+  for (long long i = (long long)(blockIdx.x - J.block0) * 256 + threadIdx.x; i < n; i += (long long)J.blocks * 256) {
+    if (!J.transpose) { J.dst[i] = (__bf16)J.src[i]; continue; }
+    const long long t = i / per, rem = i - t * per;
+    const int c = (int)(rem / J.R), r = (int)(rem - (long long)c * J.R);
+    J.dst[i] = (__bf16)J.src[t * per + (long long)r * J.C + c];
+  }
+}
+int veex_pack_weights_bf16_multi(int n, const float* const* src, void* const* dst, const int* taps, const int* rows,
+                                 const int* cols, const int* transpose, hipStream_t st) {
+  if (n < 1 || n > 16) { veex_set_error("pack_weights_bf16_multi: 1..16 jobs"); return -1; }
+  PackJobs jobs; jobs.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    const long long e = (long long)taps[i] * rows[i] * cols[i];
+    int b = (int)((e + 256 * 8 - 1) / (256 * 8));
+    if (b < 1) b = 1;
+    if (b > 256) b = 256;
+    jobs.j[i].src = src[i]; jobs.j[i].dst = reinterpret_cast<__bf16*>(dst[i]);
+    jobs.j[i].taps = taps[i]; jobs.j[i].R = rows[i]; jobs.j[i].C = cols[i]; jobs.j[i].transpose = transpose[i];
+    jobs.j[i].block0 = total; jobs.j[i].blocks = b;
+    total += b;
+  }
+  hipLaunchKernelGGL(pack_weights_bf16_multi_kernel, dim3(total), dim3(256), 0, st, jobs);
+  VEEX_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int veex_pack_weights_bf16(const float* src, void* dst, int taps, int rows, int cols, int transpose,
@@ -320,6 +355,7 @@ static int ggb_launch(const GGParams& p, dim3 grid, hipStream_t st) {
 int veex_launch_gather_gemm_bf16(GGParams& p, int mtiles, hipStream_t st) {
   if (p.Cin % 32 != 0) { veex_set_error("gather_gemm(bf16): Cin %% 32 == 0 required (got %d)", p.Cin); return -1; }
   if ((long long)p.Nb * p.Hout * p.Wout >= (1LL << 24)) { veex_set_error("gather_gemm(bf16): more than 2^24 output pixels"); return -1; }
+  if ((long long)p.Nb * p.Hout * p.Wout * p.Cout * 4 >= 0x7FFF0000LL) { veex_set_error("gather_gemm(bf16): output of 2 GiB or more"); return -1; }
   const int bm = veex_gg_bm(p);
   const int bn = (bm == 128 && p.Cout > 64) ? 128 : 64;
   const int ntiles = (p.Cout + bn - 1) / bn;

@@ -531,14 +531,17 @@ static int check_common(const VeexNet* n, const void* params, const void* state,
 // bf16 copies of the seven big kernels from the fp32 master weights (once per call: the weights change every step)
 static int run_pack_weights(Ctx& c) {
   if (c.n->compute != VEEX_COMPUTE_BF16) return 0;
+  const float* src[14]; void* dst[14]; int taps[14], rows[14], cols[14], tr[14];
   for (int i = 0; i < 7; ++i) {
     const ConvLayer& l = big_layer(c.n, i);
     // Conv2D kernels are (kh,kw,Cin,Cout), Conv2DTranspose kernels (kh,kw,Cout,Cin)
-    const int rows = (i < 2) ? l.Cin : l.Cout, cols = (i < 2) ? l.Cout : l.Cin;
-    TRY(veex_pack_weights_bf16(c.P + l.w, c.ws + c.plan.wpack[i][0], l.k * l.k, rows, cols, 0, c.st));
-    TRY(veex_pack_weights_bf16(c.P + l.w, c.ws + c.plan.wpack[i][1], l.k * l.k, rows, cols, 1, c.st));
+    for (int t = 0; t < 2; ++t) {
+      const int k = 2 * i + t;
+      src[k] = c.P + l.w; dst[k] = c.ws + c.plan.wpack[i][t]; taps[k] = l.k * l.k;
+      rows[k] = (i < 2) ? l.Cin : l.Cout; cols[k] = (i < 2) ? l.Cout : l.Cin; tr[k] = t;
+    }
   }
-  return 0;
+  return veex_pack_weights_bf16_multi(14, src, dst, taps, rows, cols, tr, c.st);
 }
 // packed weights [tap][Cout_gemm][Cin_gemm] for the forward (fwd=1) or input-gradient GEMM of big layer i
 static const void* packed_w(const Ctx& c, int i, int fwd) {

@@ -112,6 +112,8 @@ extern "C" int veex_conv1_fwd_bf16(const float* x, const float* W, const float* 
                                    const float* bn_shift, void* out_bf16, int B, hipStream_t st);
 extern "C" int veex_deconv6_bwd_bf16(const float* dlogit, const float* a5, const float* scale, const float* shift,
                                      const float* W6, float* dpre5, void* dpre5_bf16, float* slab, int B, hipStream_t st);
+int veex_pack_weights_bf16_multi(int n, const float* const* src, void* const* dst, const int* taps, const int* rows,
+                                 const int* cols, const int* transpose, hipStream_t st);
 extern "C" int veex_pack_weights_bf16(const float* src, void* dst, int taps, int rows, int cols, int transpose, hipStream_t st);
 
 void veex_set_error(const char* fmt, ...);
