@@ -324,9 +324,10 @@ static SplitPlan wgrad_split(const WGParams& pin) {
   const int tiles = veex_wg_tiles(pin, &bm, &bn);
   const int bk = (pin.bf16 == 2) ? 64 : pin.bf16 ? 32 : VEEX_BK;   // reduction rows per K chunk of the kernel that will run
   const int chunks = (pin.R + bk - 1) / bk;
-  // Blocks per launch the row split aims at: 3 per CU, all resident at once and equally long, so the launch
+  // Blocks per launch the row split aims at: what fits on the chip at once (3 per CU), equally long, so the launch
   // lasts as long as the fullest CU -- never exceed the target (774 blocks = a 4th block on six CUs = +33 %).
-  const int target = veex_env_int("VEEX_WG_BLOCKS", 768);
+  // (the bf16 copy kernel holds 72 KB of LDS: 2 blocks per CU)
+  const int target = veex_env_int("VEEX_WG_BLOCKS", (pin.bf16 == 2) ? 512 : 768);
   int ns = veex_env_int("VEEX_WG_FLOOR", 1) ? target / tiles : (target + tiles - 1) / tiles;
   const int maxs = (chunks / 4 > 0) ? chunks / 4 : 1;
   if (ns > maxs) ns = maxs;
