@@ -556,7 +556,10 @@ int veex_gg_bm(const GGParams& p) {
   if (force == 64 || force == 128) return force;
   if (p.Wbf == nullptr || p.Cin % 32 != 0) return 64;
   const long long blocks = ((M + 127) / 128) * ((p.Cout > 64) ? (p.Cout + 127) / 128 : 1);
-  return (p.epi == VEEX_EPI_BWD || blocks < 256) ? 64 : 128;
+  // BatchNorm/ReLU-backward epilogue: 64-row tiles, except the stride-1 multi-tap input gradients (deconv2, deconv4:
+  // long K loops), where 128-row tiles measure -10..-27 % since the epilogue went branch-free
+  const bool bwd64 = p.epi == VEEX_EPI_BWD && !(p.stride == 1 && p.kh * p.kw > 1);
+  return (bwd64 || blocks < 256) ? 64 : 128;
 }
 
 static int gg_bn(int Cout, int bm) {

@@ -168,7 +168,9 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GGParams p)
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
       const bool ok = cvalid && ((a_mask[i] >> tapi) & 1u);
-      st.ra[i] = bload4(rA, ok ? (unsigned)(a_rowbase[i] + delta) : VEEX_OOB);
+      unsigned aoff = ok ? (unsigned)(a_rowbase[i] + delta) : VEEX_OOB;
+      if (p.dbg & 64) aoff = ok ? (aoff & 0xFF0u) : VEEX_OOB;   // timing-only: every A load hits the same 4 KiB
+      st.ra[i] = bload4(rA, aoff);
       st.rok[i] = ok;
       if (AFF == 2) {
         const unsigned ao = ok ? (unsigned)(a_rowbase[i] + delta - a_nbase[i]) : VEEX_OOB;
