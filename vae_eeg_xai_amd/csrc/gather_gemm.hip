@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
       int j = rem / Wp, i = rem - j * Wp;
       off = (n * p.Hout + ostep * j + oy0) * p.Wout + ostep * i + ox0;
     }
-    s_off[tid] = off;
+    s_off[tid] = (off < 0) ? (int)0x80000000 : off * p.Cout * 4;   // byte offset of the fp32 output row (gg_epilogue_b)
   }
 
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
     p.Out[(long long)btile * 256 + tid] = t;
     return;
   }
-  gg_epilogue<BM, BN, WM, WN>(p, acc, s_off, As, btile, kz, n0);
+  gg_epilogue_b<BM, BN, WM, WN>(p, acc, reinterpret_cast<const unsigned*>(s_off), As, btile, kz, n0);
 }
 
 // ---------------------------------------------------------------------------
@@ -699,7 +699,7 @@ int veex_launch_gather_gemm(const GGParams& pin, hipStream_t st) {
   const long long a_bytes = (long long)p.Nb * p.Hin * p.Win * p.Cin * 4;
   const long long w_bytes = (long long)p.kh * p.kw * p.Cin * p.Cout * 4;
   const bool vec_ok = (p.Cin % 4 == 0) && (p.mode == 1 || p.Cout % 4 == 0);
-  const bool fast = vec_ok && a_bytes < 0x7FFF0000LL && w_bytes < 0x7FFF0000LL && p.kh * p.kw <= 32 &&
+  const bool fast = vec_ok && a_bytes < 0x7FFF0000LL && w_bytes < 0x7FFF0000LL && Mtot * p.Cout * 4 < 0x7FFF0000LL && p.kh * p.kw <= 32 &&
                     (p.a_scale == nullptr || !p.aff_spatial || (p.aff_mask + 1) == p.Hin * p.Win * p.Cin);
   if (p.Wbf != nullptr && fast && Mtot >= 4096 && Mtot < (1LL << 24) && Mtot * p.Cout * 4 < 0x7FFF0000LL && p.Cin % 32 == 0) return veex_launch_gather_gemm_bf16(p, mtiles, st);
   if (bm == 64 && fast && veex_env_int("VEEX_GGV3", 1) && veex_gg_v3_ok(p)) return veex_launch_gather_gemm_v3(p, mtiles, st);

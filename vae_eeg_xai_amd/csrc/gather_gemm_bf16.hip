@@ -34,18 +34,19 @@ __device__ __forceinline__ void fdivmod24(int r, int d, float inv, int& qo, int&
 
 // ABF: A comes from a bf16 consumer copy (p.Abf, BatchNorm already applied by its producer's epilogue):
 // the A tile is staged with plain 16-byte copies -- no affine, no conversion (AFF must be 0).
-template <int BM, int BN, int WM, int WN, bool MODE1, int AFF, bool ABF>
+template <int BM, int BN, int WM, int WN, bool MODE1, int AFF, bool ABF, int BK = 32>
 __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GGParams p) {
-  constexpr int BK = 32;
   constexpr int LDKH = BK + 8;         // bf16 elements per LDS row
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 32, NT = WTN / 32;
-  constexpr int AQ = ABF ? 4 : 8;      // 16-byte pieces per A row: 4 x 8 bf16 or 8 x 4 fp32
+  constexpr int AQ = ABF ? BK / 8 : BK / 4;   // 16-byte pieces per A row: 8 bf16 or 4 fp32 each
   constexpr int ARP = 256 / AQ;        // A rows staged per pass
   constexpr int APASS = BM / ARP;
   constexpr int AEB = ABF ? 2 : 4;     // bytes per A element in HBM
   static_assert(!ABF || AFF == 0, "a bf16 consumer copy already carries the BatchNorm");
-  constexpr int BPASS = BN / 64;       // B: 4 x 16 B per row, 64 rows per pass
+  constexpr int BQ = BK / 8;           // B: 16-byte pieces per row
+  constexpr int BRP = 256 / BQ;        // B rows staged per pass
+  constexpr int BPASS = BN / BRP;
   constexpr int A_ELEMS = BM * LDKH, B_ELEMS = BN * LDKH;
   static_assert(WM * WN == 4, "4 waves");
   static_assert(APASS >= 1 && BPASS >= 1, "tile too small");
@@ -140,12 +141,12 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GGParams p)
     }
   }
   // ---- B loader: rows (tid>>2)+64*i of the packed weights, 16-byte piece (tid&3) = 8 k values ----
-  const int bq = tid & 3, br = tid >> 2;
+  const int bq = tid % BQ, br = tid / BQ;
   int b_rowbase[BPASS];
   bool b_ok[BPASS];
 #pragma unroll
   for (int i = 0; i < BPASS; ++i) {
-    const int n = n0 + br + 64 * i;
+    const int n = n0 + br + BRP * i;
     b_ok[i] = n < p.Cout;
     b_rowbase[i] = (n * p.Cin + 8 * bq) * 2;
   }
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GGParams p)
     }
 #pragma unroll
     for (int i = 0; i < BPASS; ++i)
-      *reinterpret_cast<uint4*>(bs + (br + 64 * i) * LDKH + 8 * bq) = st.rb[i];
+      *reinterpret_cast<uint4*>(bs + (br + BRP * i) * LDKH + 8 * bq) = st.rb[i];
   };
 
   f32x16 acc[MT][NT];
@@ -337,15 +338,31 @@ extern "C" int veex_pack_weights_bf16(const float* src, void* dst, int taps, int
 // ---------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------
-template <int BM, int BN>
-static constexpr size_t ggb_lds_bytes() { return (2 * BM * 40 + 2 * BN * 40) * 2 + BM * sizeof(int); }
+template <int BM, int BN, int BK = 32>
+static constexpr size_t ggb_lds_bytes() { return (2 * BM * (BK + 8) + 2 * BN * (BK + 8)) * 2 + BM * sizeof(int); }
 
 template <int BM, int BN, bool MODE1>
 static int ggb_launch(const GGParams& p, dim3 grid, hipStream_t st) {
   constexpr size_t lds = ggb_lds_bytes<BM, BN>();
   static_assert(lds <= 64 * 1024, "fits the default dynamic LDS limit");
   const int aff = (p.a_scale == nullptr) ? 0 : (p.aff_spatial ? 2 : 1);
-  if (p.Abf != nullptr) hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM, BN, 2, 2, MODE1, 0, true>), grid, dim3(256), lds, st, p);
+  if (p.Abf != nullptr) {
+    // K chunks of 64 channels (half the barriers and loop overhead, twice the LDS): VEEX_BFBK=64, Cin % 64 == 0
+    if (veex_env_int("VEEX_BFBK", 32) == 64 && p.Cin % 64 == 0) {
+      constexpr size_t lds64 = ggb_lds_bytes<BM, BN, 64>();
+      static bool attr_done = false;
+      if (!attr_done && lds64 > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gather_gemm_bf16_kernel<BM, BN, 2, 2, MODE1, 0, true, 64>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64) != hipSuccess) {
+          veex_set_error("gather_gemm(bf16): cannot raise the dynamic LDS limit"); return -3;
+        }
+      }
+      attr_done = true;
+      hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM, BN, 2, 2, MODE1, 0, true, 64>), grid, dim3(256), lds64, st, p);
+    } else {
+      hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM, BN, 2, 2, MODE1, 0, true>), grid, dim3(256), lds, st, p);
+    }
+  }
   else if (aff == 0) hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM, BN, 2, 2, MODE1, 0, false>), grid, dim3(256), lds, st, p);
   else if (aff == 1) hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM, BN, 2, 2, MODE1, 1, false>), grid, dim3(256), lds, st, p);
   else hipLaunchKernelGGL((gather_gemm_bf16_kernel<BM, BN, 2, 2, MODE1, 2, false>), grid, dim3(256), lds, st, p);
