@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
 #pragma unroll
       for (int j = 0; j < NV / 8; ++j) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(v[j % 8]) : "v"(y));
 #pragma unroll
-      for (int j = 0; j < NS / 8; ++j) asm volatile("s_add_u32 %0, %0, 1" : "+s"(s));
+      for (int j = 0; j < NS / 8; ++j) asm volatile("s_add_u32 %0, %0, 1" : "+s"(s) : : "scc");
     }
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
@@ -67,6 +67,9 @@ int main() {
     run<64, 0, 1, 0>("8 MFMA + 64 VALU", out, wps);
     run<0, 4, 1, 0>("8 MFMA + 4 ds_read_b128", out, wps);
     run<32, 4, 1, 0>("8 MFMA + 32 VALU + 4 ds_read_b128", out, wps);
+    run<0, 0, 1, 32>("8 MFMA + 32 SALU", out, wps);
+    run<0, 0, 1, 64>("8 MFMA + 64 SALU", out, wps);
+    run<0, 0, 2, 64>("8 MFMA (2 acc) + 64 SALU", out, wps);
   }
   return 0;
 }

@@ -677,6 +677,10 @@ static int gg_launch_cfg(GGParams& p, int mtiles, bool fast, hipStream_t st) {
 
 int veex_launch_gather_gemm(const GGParams& pin, hipStream_t st) {
   GGParams p = pin;
+  if (const int tm = veex_env_int("VEEX_TIMING", 0)) {   // timing experiments only (tools/ab_env.py): results are wrong
+    if (tm & 1) p.a_scale = p.a_shift = nullptr;          //   1: no BatchNorm prologue
+    if (tm & 2) { p.epi = VEEX_EPI_RAW; p.partials = nullptr; p.aux = nullptr; }   // 2: plain store epilogue
+  }
   if (p.stride != 1 && p.stride != 2) { veex_set_error("gather_gemm: stride %d unsupported", p.stride); return -1; }
   if (p.Nb <= 0 || p.Cin <= 0 || p.Cout <= 0 || p.Hout <= 0 || p.Wout <= 0 || p.Hin <= 0 || p.Win <= 0) {
     veex_set_error("gather_gemm: bad geometry"); return -1;

@@ -347,8 +347,12 @@ static int ggb_launch(const GGParams& p, dim3 grid, hipStream_t st) {
   static_assert(lds <= 64 * 1024, "fits the default dynamic LDS limit");
   const int aff = (p.a_scale == nullptr) ? 0 : (p.aff_spatial ? 2 : 1);
   if (p.Abf != nullptr) {
-    // K chunks of 64 channels (half the barriers and loop overhead, twice the LDS): VEEX_BFBK=64, Cin % 64 == 0
-    if (veex_env_int("VEEX_BFBK", 32) == 64 && p.Cin % 64 == 0) {
+    // K chunks of 64 channels (half the barriers and loop overhead, twice the LDS, so fewer resident blocks):
+    // measured per layer at B=512 it wins where the K loop per tap is long (Cin >= 128) and the launch is at most
+    // ~4 blocks per CU, and loses on the large grids.  VEEX_BFBK=32/64 forces one of them.
+    const int bfbk = veex_env_int("VEEX_BFBK", 0);
+    const bool auto64 = p.Cin >= 128 && (long long)grid.x <= 1024;
+    if (p.Cin % 64 == 0 && (bfbk == 64 || (bfbk == 0 && auto64))) {
       constexpr size_t lds64 = ggb_lds_bytes<BM, BN, 64>();
       static bool attr_done = false;
       if (!attr_done && lds64 > 64 * 1024) {

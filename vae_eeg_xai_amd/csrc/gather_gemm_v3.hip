@@ -23,6 +23,16 @@ __device__ __forceinline__ float4 bload4s(__amdgpu_buffer_rsrc_t r, unsigned vof
   return make_float4(f[0], f[1], f[2], f[3]);
 }
 
+// q = r / d, rem = r % d for 0 <= r < 2^24, 1 <= d < 2^24: float reciprocal + one correction step instead of the
+// ~40-instruction 32-bit integer division (four of them per thread in the prologue of every tile)
+__device__ __forceinline__ void g3_divmod(int r, int d, float inv, int& qo, int& rem) {
+  int q = (int)((float)r * inv);
+  int m = r - q * d;
+  if (m < 0) { q -= 1; m += d; }
+  if (m >= d) { q += 1; m -= d; }
+  qo = q; rem = m;
+}
+
 template <bool MODE1, int AFF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void gather_gemm_v3_kernel(const GGParams p) {
   constexpr int BM = 64, BN = 64, BK = 16;
@@ -67,13 +77,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   const int c_begin = kz * p.chunks_per_split;
   const int c_end = min(nchunks, c_begin + p.chunks_per_split);
   const int HWp = Hp * Wp;
+  const float invHWp = 1.0f / (float)HWp, invWp = 1.0f / (float)Wp;   // rows < 2^24 (veex_gg_v3_ok)
 
   if (tid < BM) {
     const int m = m0 + tid;
     unsigned off = 0x80000000u;   // + any column offset stays out of range: the store is dropped
     if (m < Mph) {
-      const int n = m / HWp, rem = m - n * HWp;
-      const int j = rem / Wp, i = rem - j * Wp;
+      int n, rem, j, i;
+      g3_divmod(m, HWp, invHWp, n, rem);
+      g3_divmod(rem, Wp, invWp, j, i);
       off = (unsigned)(((n * p.Hout + ostep * j + oy0) * p.Wout + ostep * i + ox0) * p.Cout) * 4u;
     }
     s_offb[tid] = off;
@@ -103,8 +115,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   {
     const int m = m0 + lr;
     if (m < Mph) {
-      const int n = m / HWp, rem = m - n * HWp;
-      const int j = rem / Wp, ii = rem - j * Wp;
+      int n, rem, j, ii;
+      g3_divmod(m, HWp, invHWp, n, rem);
+      g3_divmod(rem, Wp, invWp, j, ii);
       const int oy = ostep * j + oy0, ox = ostep * ii + ox0;
       int by, bx;   // input pixel read by phase tap (0,0)
       if (MODE1) { by = (oy + p.pb - kys) >> (p.stride - 1); bx = (ox + p.pb - kxs) >> (p.stride - 1); }
@@ -323,6 +336,7 @@ int veex_gg_v3_ok(const GGParams& p) {
   const long long o_bytes = (long long)p.Nb * p.Hout * p.Wout * p.Cout * 4;
   const long long w_bytes = (long long)p.kh * p.kw * p.Cin * p.Cout * 4;
   if (p.Cin % 16 != 0 || p.kh * p.kw > 31) return 0;
+  if ((long long)p.Nb * p.Hout * p.Wout >= (1LL << 24)) return 0;
   if (p.mode == 0 && p.Cout % 4 != 0) return 0;
   if (a_bytes + bias >= 0x7FFF0000LL || o_bytes >= 0x7FFF0000LL || w_bytes >= 0x7FFF0000LL) return 0;
   if (p.OutBf != nullptr || p.Abf != nullptr) return 0;

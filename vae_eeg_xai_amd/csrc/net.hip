@@ -369,8 +369,8 @@ struct Plan {
   long long act_conv[3], act_h, mulv, eps, z;
   long long act_dd, act_dc[5], dlogit, rec_b, kl_b, dlsum_b;
   long long d_conv[3], d_h, dmulv, dz, d_dd, g_dd, d_dc[5];
-  long long slab, slab_side, partials, losses_tmp;
-  long long slab_n, partials_n;
+  long long slab, slab_side, partials, partials2, losses_tmp;
+  long long slab_n, partials_n, partials2_n;
   long long wpack[7][2];
   // bf16 consumer copies (bf16 compute only; -1 otherwise): BatchNorm-applied activations and gradients
   long long bf_act_conv[2], bf_act_dd, bf_act_dc[4], bf_d_dc[5], bf_d_conv[3];   // bf16 weight copies (floats offset): layers conv2, conv3, deconv1..5; [0] as stored, [1] transposed
@@ -457,18 +457,24 @@ static void make_plan(const VeexNet* n, int B, Plan& P) {
     const int mt2 = (int)gg_tiles_for(B, 1, L, 1, 1, 0);
     upd(slab, (long long)gg_split(mt2, L, 4096 / VEEX_BK) * B * L);
   }
-  // partials: EPI_BWD launches (m_tiles * 3 * Cout) and row-chunk launches
+  // partials: every producer of one backward pass keeps its own rows until the batched finalisation at the end of
+  // the pass (take_partials): EPI_BWD launches (m_tiles * 3 * Cout), row-chunk launches, the deconv6 backward rows
+  auto acc = [](long long& m, long long v) { m += (v + 63) & ~63LL; };
   for (int i = 1; i < 5; ++i)  // dgrad of deconv i+1 produces gradient of deconv i's output
-    upd(part, gg_tiles_for(B, n->dc[i - 1].Hout, n->dc[i - 1].Cout, 0, 1, 0) * 3 * n->dc[i - 1].Cout);
-  upd(part, gg_tiles_for(B, 1, 6400, 1, 1, 0) * 3 * 6400);
-  upd(part, gg_tiles_for(B, 10, 128, 1, 2, 0) * 3 * 128);
-  upd(part, gg_tiles_for(B, 20, 64, 1, 2, 0) * 3 * 64);
-  upd(part, gg_tiles_for(B, 1, H1, 1, 1, 0) * 3 * H1);
-  upd(part, (long long)veex_bnrelu_bwd_rows_chunks(B) * 3 * 4096);
+    acc(part, gg_tiles_for(B, n->dc[i - 1].Hout, n->dc[i - 1].Cout, 0, 1, 0) * 3 * n->dc[i - 1].Cout);
+  acc(part, gg_tiles_for(B, 1, 6400, 1, 1, 0) * 3 * 6400);
+  acc(part, gg_tiles_for(B, 10, 128, 1, 2, 0) * 3 * 128);
+  acc(part, gg_tiles_for(B, 20, 64, 1, 2, 0) * 3 * 64);
+  acc(part, gg_tiles_for(B, 1, H1, 1, 1, 0) * 3 * H1);
+  acc(part, (long long)veex_bnrelu_bwd_rows_chunks(B) * 3 * 4096);
+  acc(part, (long long)veex_bnrelu_bwd_rows_chunks(B) * 3 * (2 * L > H1 ? 2 * L : H1));
+  acc(part, (long long)B * 448);
   P.slab_n = slab; P.partials_n = part;
   P.slab = w.add("scratch.slab", slab);
   P.slab_side = w.add("scratch.slab_side", slab);   // weight-gradient slabs when they run on the side stream
   P.partials = w.add("scratch.partials", part);
+  P.partials2_n = (long long)VEEX_COLSUM_MAX * VEEX_PARTIALS2_N;
+  P.partials2 = w.add("scratch.partials2", P.partials2_n);   // compacted partial rows (veex_colsum_batch)
   P.bf_act_conv[0] = P.bf_act_conv[1] = P.bf_act_dd = -1;
   for (int i = 0; i < 4; ++i) P.bf_act_dc[i] = -1;
   for (int i = 0; i < 5; ++i) P.bf_d_dc[i] = -1;
@@ -505,6 +511,7 @@ extern "C" long long veex_net_ws_offset(const VeexNet* n, int B, const char* nam
 // execution helpers
 // ------------------------------------------------------------------------------------------
 struct Ctx {
+  Ctx() { fin.n = 0; }
   hipStream_t side = nullptr;   // non-null: weight-gradient GEMMs are forked onto this stream
   bool forked = false;
   const VeexNet* n;
@@ -514,6 +521,8 @@ struct Ctx {
   Plan plan;
   int B;
   hipStream_t st;
+  long long part_cur = 0;       // bump cursor into scratch.partials: every producer of one pass keeps its own rows
+  ColsumBatch fin;              // column-sum finalisations collected during the backward pass (flush_colsum)
   const float* scale(int bn) const { return ws + plan.bn_scale + bn; }
   const float* shift(int bn) const { return ws + plan.bn_shift + bn; }
   const float* rstd(int bn) const { return ws + plan.bn_rstd + bn; }
@@ -680,23 +689,52 @@ static int run_wgrad(Ctx& c, WGParams& p, float* dW) {
   return veex_slab_sum(slab, s.nsplit, n, n, dW, nullptr, 1, 0, st);
 }
 
+static float* take_partials(Ctx& c, long long nfloats) {
+  if (c.part_cur + nfloats > c.plan.partials_n) { veex_set_error("internal: partials scratch too small"); return nullptr; }
+  float* p = c.ws + c.plan.partials + c.part_cur;
+  c.part_cur += (nfloats + 63) & ~63LL;
+  return p;
+}
+static int defer_colsum(Ctx& c, const float* partials, int T, long long row_stride, int ncols, int nch, const float* e_scale,
+                        const float* mean, const float* rstd, float* dbias, float* dgamma, float* dbeta) {
+  if (c.fin.n >= VEEX_COLSUM_MAX) { veex_set_error("internal: column-sum table full"); return VEEX_EINVAL; }
+  ColsumEntry& e = c.fin.e[c.fin.n++];
+  memset(&e, 0, sizeof(e));
+  e.partials = partials; e.T = T; e.row_stride = row_stride; e.ncols = ncols; e.nch = nch;
+  e.e_scale = e_scale; e.mean = mean; e.rstd = rstd; e.dbias = dbias; e.dgamma = dgamma; e.dbeta = dbeta;
+  if (!veex_env_int("VEEX_COLSUM_DEFER", 1)) {   // A/B switch: finalise right away (two launches per entry)
+    const int rc = veex_colsum_batch(c.fin, c.ws + c.plan.partials2, c.plan.partials2_n, c.st);
+    c.fin.n = 0;
+    return rc;
+  }
+  return 0;
+}
+static int flush_colsum(Ctx& c) {
+  const int rc = veex_colsum_batch(c.fin, c.ws + c.plan.partials2, c.plan.partials2_n, c.st);
+  c.fin.n = 0;
+  return rc;
+}
+
 // dgrad GEMM with BN/ReLU-backward epilogue + finalisation of the producing layer's bias/gamma/beta grads
 static int dgrad_bwd(Ctx& c, GGParams& p, const ConvLayer& prod, const float* aux, float* dpre, float* G, int want_param_grads) {
   const VeexNet* n = c.n;
   p.Out = dpre; p.aux = aux; p.epi = VEEX_EPI_BWD; p.relu = 1; p.nsplit = 1;
   if (prod.bn >= 0) { p.e_scale = c.scale(prod.bn); p.epi_cmask = prod.bnC - 1; }
-  p.partials = want_param_grads ? c.ws + c.plan.partials : nullptr;
   GGParams q = p;
   const int mt = veex_gg_m_tiles(q);
-  if (want_param_grads && (long long)mt * 3 * p.Cout > c.plan.partials_n) { veex_set_error("internal: partials scratch too small"); return VEEX_ENOMEM; }
+  p.partials = nullptr;
+  if (want_param_grads) {
+    p.partials = take_partials(c, (long long)mt * 3 * p.Cout);
+    if (p.partials == nullptr) return VEEX_ENOMEM;
+  }
   TRY(veex_launch_gather_gemm(p, c.st));
   if (!want_param_grads) return 0;
   const int nch = (prod.bn >= 0) ? prod.bnC : p.Cout;
-  return veex_colsum_finalize(c.ws + c.plan.partials, mt, 3LL * p.Cout, p.Cout, nch,
-                              prod.bn >= 0 ? c.scale(prod.bn) : nullptr, prod.bn >= 0 ? c.mean(prod.bn) : nullptr,
-                              prod.bn >= 0 ? c.rstd(prod.bn) : nullptr, G + prod.b,
-                              prod.bn >= 0 ? G + n->gamma_off + prod.bn : nullptr,
-                              prod.bn >= 0 ? G + n->beta_off + prod.bn : nullptr, c.st);
+  return defer_colsum(c, p.partials, mt, 3LL * p.Cout, p.Cout, nch,
+                      prod.bn >= 0 ? c.scale(prod.bn) : nullptr, prod.bn >= 0 ? c.mean(prod.bn) : nullptr,
+                      prod.bn >= 0 ? c.rstd(prod.bn) : nullptr, G + prod.b,
+                      prod.bn >= 0 ? G + n->gamma_off + prod.bn : nullptr,
+                      prod.bn >= 0 ? G + n->beta_off + prod.bn : nullptr);
 }
 
 // encoder backward from d(pre-activation of enc.dense) in ws+d_h down to d(pre-act conv1) in ws+d_conv[0]
@@ -854,11 +892,13 @@ extern "C" int veex_net_train_fwd_bwd(const VeexNet* n, const float* params, con
   // ---- backward (tape.gradient, models.py:166) ----
   {  // deconv6 + BN5/ReLU backward
     const ConvLayer& l5 = n->dc[4];
+    float* d6 = take_partials(c, (long long)B * 448);   // rows 0-3 dW6 partials, rows 4-6 the three column sums
+    if (d6 == nullptr) return VEEX_ENOMEM;
     TRY(veex_deconv6_bwd_bf16(ws + P.dlogit, ws + P.act_dc[4], c.scale(l5.bn), c.shift(l5.bn), c.P + n->dc[5].w,
-                              ws + P.d_dc[4], bfp(c, P.bf_d_dc[4]), ws + P.slab, B, st));
-    TRY(veex_slab_sum(ws + P.slab, B, 448, 256, G + n->dc[5].w, nullptr, 1, 0, st));
-    TRY(veex_colsum_finalize(ws + P.slab + 256, B, 448, 64, 64, c.scale(l5.bn), c.mean(l5.bn), c.rstd(l5.bn), G + l5.b,
-                             G + n->gamma_off + l5.bn, G + n->beta_off + l5.bn, st));
+                              ws + P.d_dc[4], bfp(c, P.bf_d_dc[4]), d6, B, st));
+    TRY(veex_slab_sum(d6, B, 448, 256, G + n->dc[5].w, nullptr, 1, 0, st));
+    TRY(defer_colsum(c, d6 + 256, B, 448, 64, 64, c.scale(l5.bn), c.mean(l5.bn), c.rstd(l5.bn), G + l5.b,
+                     G + n->gamma_off + l5.bn, G + n->beta_off + l5.bn));
   }
   for (int i = 4; i >= 0; --i) {
     const ConvLayer& l = n->dc[i];
@@ -883,9 +923,11 @@ extern "C" int veex_net_train_fwd_bwd(const VeexNet* n, const float* params, con
       p.Out = ws + P.g_dd; p.epi = VEEX_EPI_FWD; p.relu = 0; p.bias = nullptr; p.nsplit = 1;
       TRY(veex_launch_gather_gemm(p, st));
       const int chunks = veex_bnrelu_bwd_rows_chunks(B);
-      TRY(veex_bnrelu_bwd_rows(ws + P.g_dd, ws + P.act_dd, c.scale(prod.bn), ws + P.d_dd, ws + P.partials, B, 4096, 4096, st));
-      TRY(veex_colsum_finalize(ws + P.partials, chunks, 3LL * 4096, 4096, 4096, c.scale(prod.bn), c.mean(prod.bn),
-                               c.rstd(prod.bn), G + prod.b, G + n->gamma_off + prod.bn, G + n->beta_off + prod.bn, st));
+      float* part = take_partials(c, (long long)chunks * 3 * 4096);
+      if (part == nullptr) return VEEX_ENOMEM;
+      TRY(veex_bnrelu_bwd_rows(ws + P.g_dd, ws + P.act_dd, c.scale(prod.bn), ws + P.d_dd, part, B, 4096, 4096, st));
+      TRY(defer_colsum(c, part, chunks, 3LL * 4096, 4096, 4096, c.scale(prod.bn), c.mean(prod.bn),
+                       c.rstd(prod.bn), G + prod.b, G + n->gamma_off + prod.bn, G + n->beta_off + prod.bn));
     }
   }
   {  // dec.dense: dW = z^T . dpre ; dz = dpre . W^T (split-K)
@@ -910,9 +952,10 @@ extern "C" int veex_net_train_fwd_bwd(const VeexNet* n, const float* params, con
     TRY(veex_reparam_kl_bwd(ws + P.dz, ws + P.mulv, ws + P.eps, ws + P.dmulv, B, L, 1.0f / B, st));
     {  // head biases: column sums of dmulv
       const int chunks = veex_bnrelu_bwd_rows_chunks(B);
-      TRY(veex_bnrelu_bwd_rows(ws + P.dmulv, nullptr, nullptr, nullptr, ws + P.partials, B, 2 * L, 0, st));
-      TRY(veex_colsum_finalize(ws + P.partials, chunks, 3LL * 2 * L, 2 * L, 2 * L, nullptr, nullptr, nullptr, G + n->bh,
-                               nullptr, nullptr, st));
+      float* part = take_partials(c, (long long)chunks * 3 * 2 * L);
+      if (part == nullptr) return VEEX_ENOMEM;
+      TRY(veex_bnrelu_bwd_rows(ws + P.dmulv, nullptr, nullptr, nullptr, part, B, 2 * L, 0, st));
+      TRY(defer_colsum(c, part, chunks, 3LL * 2 * L, 2 * L, 2 * L, nullptr, nullptr, nullptr, G + n->bh, nullptr, nullptr));
     }
     {  // dWh = h^T . dmulv
       WGParams w; memset(&w, 0, sizeof(w));
@@ -930,11 +973,13 @@ extern "C" int veex_net_train_fwd_bwd(const VeexNet* n, const float* params, con
     }
   } else {  // AE: z is the ReLU bottleneck itself (models_standard.py:108)
     const int chunks = veex_bnrelu_bwd_rows_chunks(B);
-    TRY(veex_bnrelu_bwd_rows(ws + P.dz, ws + P.act_h, nullptr, ws + P.d_h, ws + P.partials, B, H1, 0, st));
-    TRY(veex_colsum_finalize(ws + P.partials, chunks, 3LL * H1, H1, H1, nullptr, nullptr, nullptr, G + n->dense.b,
-                             nullptr, nullptr, st));
+    float* part = take_partials(c, (long long)chunks * 3 * H1);
+    if (part == nullptr) return VEEX_ENOMEM;
+    TRY(veex_bnrelu_bwd_rows(ws + P.dz, ws + P.act_h, nullptr, ws + P.d_h, part, B, H1, 0, st));
+    TRY(defer_colsum(c, part, chunks, 3LL * H1, H1, H1, nullptr, nullptr, nullptr, G + n->dense.b, nullptr, nullptr));
   }
   TRY(encoder_backward(c, x, G, 1));
+  TRY(flush_colsum(c));
   return join_side(c);
 }
 

@@ -105,41 +105,47 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
   }
 }
 
+// sum over the 16 lanes of a DPP row with four v_add_f32 ... dpp (quad xor 1, quad xor 2, half-row mirror, row
+// mirror) instead of four ds_bpermute round trips through the LDS pipe; every lane of the row gets the total
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);   // row_half_mirror
+  v = dpp_add<0x140>(v);   // row_mirror
+  return v;
+}
+
 // dx[n][iy][ix] = sum_{ky,kx,co} dpre1[n][(iy-ky)/2][(ix-kx)/2][co] * W1[ky][kx][co]  (attribution only)
-// One block per sample, dpre1 streamed exactly once:
-//   phase 1: per conv1 output pixel the 9 tap dot products over 64 channels (4 lanes x 16 channels,
-//            weights broadcast from LDS, 2-step shuffle reduce) -> T[400][9] in LDS
+// One block per sample, dpre1 streamed exactly once (coalesced float4 per lane, next pixel prefetched):
+//   phase 1: per conv1 output pixel the 9 tap dot products over 64 channels (16 lanes x 4 channels, the 9x4
+//            weights in registers, DPP row sums) -> T[400][9] in LDS
 //   phase 2: per input pixel gather its <= 4 contributions from T, times mul (gradient*input), store.
 __global__ __launch_bounds__(256) void conv1_dgrad_kernel(const float* __restrict__ dpre, const float* __restrict__ W,
                                                           const float* __restrict__ mul, float* __restrict__ dx) {
-  __shared__ __attribute__((aligned(16))) float sW[9 * NCH];
   __shared__ float sT[C1H * C1H * 9];
   const int n = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < 9 * NCH; i += 256) sW[i] = W[i];
-  __syncthreads();
-  const int l4 = tid & 3, g = tid >> 2;
-  const float* src = dpre + (long long)n * (C1H * C1H * NCH) + 16 * l4;
-  for (int pix = g; pix < C1H * C1H; pix += 64) {
-    float4 v[4];
+  const int cq = tid & 15, pg = tid >> 4;
+  float4 w[9];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const float4*>(src + (long long)pix * NCH + 4 * c);
-    float acc[9];
+  for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const float4*>(W + t * NCH + 4 * cq);
+  const float* src = dpre + (long long)n * (C1H * C1H * NCH) + 4 * cq;
+  float4 nxt = *reinterpret_cast<const float4*>(src + pg * NCH);
+  for (int pix = pg; pix < C1H * C1H; pix += 16) {
+    const float4 v = nxt;
+    if (pix + 16 < C1H * C1H) nxt = *reinterpret_cast<const float4*>(src + (pix + 16) * NCH);
+    float keep = 0.f;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      float a = 0.f;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float4 w = *reinterpret_cast<const float4*>(sW + t * NCH + 16 * l4 + 4 * c);
-        a = fmaf(v[c].x, w.x, a); a = fmaf(v[c].y, w.y, a); a = fmaf(v[c].z, w.z, a); a = fmaf(v[c].w, w.w, a);
-      }
-      a += __shfl_xor(a, 1);
-      a += __shfl_xor(a, 2);
-      acc[t] = a;
+      float a = v.x * w[t].x;
+      a = fmaf(v.y, w[t].y, a); a = fmaf(v.z, w[t].z, a); a = fmaf(v.w, w[t].w, a);
+      a = row16_sum(a);
+      keep = (cq == t) ? a : keep;
     }
-    if (l4 == 0) {
-#pragma unroll
-      for (int t = 0; t < 9; ++t) sT[pix * 9 + t] = acc[t];
-    }
+    if (cq < 9) sT[pix * 9 + cq] = keep;
   }
   __syncthreads();
   for (int o = tid; o < IMG * IMG; o += 256) {
@@ -168,19 +174,6 @@ __global__ __launch_bounds__(256) void conv1_dgrad_kernel(const float* __restric
 // phase 2: per output pixel gather <=4 of them, BCE, dlogit = (sigmoid - t)/B, block reduction.
 // ---------------------------------------------------------------------------------------
 #define D6_THREADS 512
-// sum over the 16 lanes of a DPP row with four v_add_f32 ... dpp (quad xor 1, quad xor 2, half-row mirror, row
-// mirror) instead of four ds_bpermute round trips through the LDS pipe; every lane of the row gets the total
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float row16_sum(float v) {
-  v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
-  v = dpp_add<0x141>(v);   // row_half_mirror
-  v = dpp_add<0x140>(v);   // row_mirror
-  return v;
-}
 __global__ __launch_bounds__(D6_THREADS) void deconv6_bce_fwd_kernel(
     const float* __restrict__ a5, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ W6, const float* __restrict__ b6, const float* __restrict__ target,
@@ -438,14 +431,11 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_rows_kernel(const float* __res
 // Column-sum finalisation: channel ch collects every column j with (j % nch) == ch over all
 // T partial rows.  dbeta = S1, dgamma = rstd*(S2 - mean*S1), dbias = escale*S3.
 // partial element (t,k,j) lives at partials[t*row_stride + k*ncols + j].  One block per channel.
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partials, int T,
-                                                              long long row_stride, int ncols, int nch,
-                                                              const float* __restrict__ e_scale,
-                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                              float* __restrict__ dbias, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta) {
-  __shared__ float red[3 * 4];
-  const int ch = blockIdx.x;
+__device__ __forceinline__ void colsum_finalize_body(const float* __restrict__ partials, int T, long long row_stride,
+                                                     int ncols, int nch, const float* __restrict__ e_scale,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     float* __restrict__ dbias, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int ch, float* red) {
   const int nrep = ncols / nch;
   float s1 = 0.f, s2 = 0.f, s3 = 0.f;
   const int total = T * nrep;
@@ -466,6 +456,73 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
     if (dbeta != nullptr) dbeta[ch] = s1;
     if (dgamma != nullptr) dgamma[ch] = rstd[ch] * (s2 - mean[ch] * s1);
   }
+}
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partials, int T,
+                                                              long long row_stride, int ncols, int nch,
+                                                              const float* __restrict__ e_scale,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              float* __restrict__ dbias, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta) {
+  __shared__ float red[3 * 4];
+  colsum_finalize_body(partials, T, row_stride, ncols, nch, e_scale, mean, rstd, dbias, dgamma, dbeta, blockIdx.x, red);
+}
+
+// First stage for tall partial matrices (an EPI_BWD launch leaves one row per 64-row tile: 11552 rows of 3*Cout at
+// batch 512, which one block per channel reads 4 strided bytes at a time): chunk c of `rpc` rows -> one row,
+// out[c][W], read coalesced (W < 256: 256/W rows in flight, folded through LDS).  The finalisation then runs
+// on the <= 256 compacted rows.  Sums in a fixed order: deterministic.
+__device__ __forceinline__ void colsum_compact_body(const float* __restrict__ partials, int T, long long row_stride,
+                                                    int W, int rpc, float* __restrict__ out, int chunk, int cgroup,
+                                                    float* red) {
+  const int tid = threadIdx.x;
+  const int R = (W >= 256) ? 1 : 256 / W;
+  const int r = (W >= 256) ? 0 : tid / W;
+  const int col = (W >= 256) ? cgroup * 256 + tid : tid - r * W;
+  const bool live = (r < R) && (col < W);
+  const int t0 = chunk * rpc, t1 = min(T, t0 + rpc);
+  float s = 0.f;
+  if (live) {
+    const float* pp = partials + col;
+    int t = t0 + r;
+    for (; t + 3 * R < t1; t += 4 * R) {
+      const float v0 = pp[(long long)t * row_stride], v1 = pp[(long long)(t + R) * row_stride];
+      const float v2 = pp[(long long)(t + 2 * R) * row_stride], v3 = pp[(long long)(t + 3 * R) * row_stride];
+      s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; t < t1; t += R) s += pp[(long long)t * row_stride];
+  }
+  if (R > 1) {
+    red[tid] = live ? s : 0.f;
+    __syncthreads();
+    if (tid < W) {
+      float a = red[tid];
+      for (int k = 1; k < R; ++k) a += red[k * W + tid];
+      out[(long long)chunk * W + tid] = a;
+    }
+  } else if (live) {
+    out[(long long)chunk * W + col] = s;
+  }
+}
+// both stages for a whole table of partial matrices (one backward pass): block -> entry by its first block
+__global__ __launch_bounds__(256) void colsum_compact_batch_kernel(const ColsumBatch b, float* __restrict__ scratch) {
+  __shared__ float red[256];
+  int k = 0;
+  for (int i = 1; i < b.n; ++i) if ((int)blockIdx.x >= b.e[i].blk_c) k = i;   // blk_c ascending; empty entries repeat it
+  while (k > 0 && b.e[k].nchunks == 0) --k;
+  const ColsumEntry& e = b.e[k];
+  const int local = (int)blockIdx.x - e.blk_c;
+  colsum_compact_body(e.partials, e.T, e.row_stride, 3 * e.ncols, e.rpc, scratch + e.scr_off, local / e.cgroups,
+                      local % e.cgroups, red);
+}
+__global__ __launch_bounds__(256) void colsum_finalize_batch_kernel(const ColsumBatch b, const float* __restrict__ scratch) {
+  __shared__ float red[3 * 4];
+  int k = 0;
+  for (int i = 1; i < b.n; ++i) if ((int)blockIdx.x >= b.e[i].blk_f) k = i;
+  const ColsumEntry& e = b.e[k];
+  const bool cmp = e.nchunks > 0;
+  colsum_finalize_body(cmp ? scratch + e.scr_off : e.partials, cmp ? e.nchunks : e.T,
+                       cmp ? 3LL * e.ncols : e.row_stride, e.ncols, e.nch, e.e_scale, e.mean, e.rstd, e.dbias, e.dgamma,
+                       e.dbeta, (int)blockIdx.x - e.blk_f, red);
 }
 
 // out[i] = epi( sum_s slab[s*stride + i] ),  epi = (+bias[i % ncols]) (relu)
@@ -726,6 +783,39 @@ int veex_colsum_finalize(const float* partials, int T, long long row_stride, int
   VEEX_CHECK_LAUNCH();
   return 0;
 }
+
+}  // extern "C"
+
+// All finalisations of one pass: tall matrices (T >= 512) are compacted first (one launch for all of them), then one
+// launch finalises every channel of every entry.  Fills the grid bookkeeping of `b`.
+int veex_colsum_batch(ColsumBatch& b, float* scratch, long long scratch_n, hipStream_t st) {
+  if (b.n < 1) return 0;
+  int nc = 0, nf = 0;
+  long long off = 0;
+  for (int i = 0; i < b.n; ++i) {
+    ColsumEntry& e = b.e[i];
+    if (e.nch <= 0 || e.ncols % e.nch != 0) { veex_set_error("colsum_batch: channel count %d must divide ncols %d", e.nch, e.ncols); return -1; }
+    const int W = 3 * e.ncols;
+    e.rpc = 1; e.nchunks = 0; e.cgroups = 1; e.blk_c = nc; e.blk_f = nf; e.scr_off = off;
+    if (e.T >= 512 && scratch != nullptr) {
+      const int rpc = (e.T + 255) / 256, nchunks = (e.T + rpc - 1) / rpc;
+      if (off + (long long)nchunks * W <= scratch_n) {
+        e.rpc = rpc; e.nchunks = nchunks; e.cgroups = (W >= 256) ? (W + 255) / 256 : 1;
+        nc += nchunks * e.cgroups; off += (long long)nchunks * W;
+      }
+    }
+    nf += e.nch;
+  }
+  if (nc > 0) {
+    hipLaunchKernelGGL(colsum_compact_batch_kernel, dim3(nc), dim3(256), 0, st, b, scratch);
+    VEEX_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(colsum_finalize_batch_kernel, dim3(nf), dim3(256), 0, st, b, (const float*)scratch);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" {
 
 int veex_slab_sum(const float* slab, int nsplit, long long stride, long long n, float* out, const float* bias,
                    int ncols, int relu, hipStream_t st) {

@@ -105,6 +105,19 @@ int veex_gg_bm(const GGParams& p);
 int veex_wg_tiles(const WGParams& p, int* bm, int* bn);
 int veex_wgrad_bf16_ok(const WGParams& p);                       // wgrad_gemm_bf16.hip
 #define VEEX_WG3_MAX_ROWS 3072                                    // rows_per_split the LDS row table of wgrad_gemm_v3.hip holds
+#define VEEX_PARTIALS2_N (256LL * 768)   // floats: 256 compacted rows of 3 x 256 channels (one entry of veex_colsum_batch)
+// Every column-sum finalisation of one backward pass in two launches (instead of up to 17 of ~5 us each):
+// the entries are collected while the pass is enqueued and run once at its end (only Adam reads the results).
+#define VEEX_COLSUM_MAX 12
+struct ColsumEntry {
+  const float* partials; int T; long long row_stride; int ncols, nch;     // as veex_colsum_finalize
+  const float *e_scale, *mean, *rstd; float *dbias, *dgamma, *dbeta;
+  int rpc, nchunks, cgroups;      // compaction: rows per chunk, chunks (0: not compacted), 256-column groups
+  int blk_c, blk_f;               // first block of this entry in the compaction / finalisation grid
+  long long scr_off;              // its compacted rows in the scratch
+};
+struct ColsumBatch { int n; ColsumEntry e[VEEX_COLSUM_MAX]; };
+int veex_colsum_batch(ColsumBatch& b, float* scratch, long long scratch_n, hipStream_t st);   // special.hip
 int veex_wgrad_v3_ok(const WGParams& p);                         // wgrad_gemm_v3.hip
 int veex_launch_wgrad_v3(const WGParams& p, int bm, int bn, hipStream_t st);
 int veex_launch_wgrad_bf16(const WGParams& p, hipStream_t st);
