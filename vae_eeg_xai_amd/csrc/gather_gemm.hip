@@ -675,6 +675,27 @@ static int gg_launch_cfg(GGParams& p, int mtiles, bool fast, hipStream_t st) {
   return 0;
 }
 
+// fast path: 16-byte buffer loads everywhere, 32-bit byte offsets, tap-validity bit mask
+static bool gg_fast_ok(const GGParams& p) {
+  const long long Mtot = (long long)p.Nb * p.Hout * p.Wout;
+  const long long a_bytes = (long long)p.Nb * p.Hin * p.Win * p.Cin * 4;
+  const long long w_bytes = (long long)p.kh * p.kw * p.Cin * p.Cout * 4;
+  const bool vec_ok = (p.Cin % 4 == 0) && (p.mode == 1 || p.Cout % 4 == 0);
+  return vec_ok && a_bytes < 0x7FFF0000LL && w_bytes < 0x7FFF0000LL && Mtot * p.Cout * 4 < 0x7FFF0000LL && p.kh * p.kw <= 32 &&
+         (p.a_scale == nullptr || !p.aff_spatial || (p.aff_mask + 1) == p.Hin * p.Win * p.Cin);
+}
+// the launch goes to the bf16 engine (gather_gemm_bf16.hip)
+static bool gg_bf16_dispatch(const GGParams& p, bool fast) {
+  const long long Mtot = (long long)p.Nb * p.Hout * p.Wout;
+  return p.Wbf != nullptr && fast && Mtot >= 4096 && Mtot < (1LL << 24) && Mtot * p.Cout * 4 < 0x7FFF0000LL && p.Cin % 32 == 0;
+}
+// 1 if this launch would run on the bf16 engine reading only the bf16 copy of its A operand (then nobody reads the
+// fp32 A), and 2 if in addition it can write its bf16 output copy alone (Out may be null)
+int veex_gg_bf16_only(const GGParams& p) {
+  if (!gg_bf16_dispatch(p, gg_fast_ok(p)) || p.Abf == nullptr) return 0;
+  return (p.OutBf != nullptr && p.epi != VEEX_EPI_RAW) ? 2 : 1;
+}
+
 int veex_launch_gather_gemm(const GGParams& pin, hipStream_t st) {
   GGParams p = pin;
   if (const int tm = veex_env_int("VEEX_TIMING", 0)) {   // timing experiments only (tools/ab_env.py): results are wrong
@@ -699,13 +720,9 @@ int veex_launch_gather_gemm(const GGParams& pin, hipStream_t st) {
   if (p.nsplit == 1) p.chunks_per_split = 1 << 30;
   const int bm = veex_gg_bm(p);
   const int bn = gg_bn(p.Cout, bm);
-  // fast path: 16-byte buffer loads everywhere, 32-bit byte offsets, tap-validity bit mask
-  const long long a_bytes = (long long)p.Nb * p.Hin * p.Win * p.Cin * 4;
-  const long long w_bytes = (long long)p.kh * p.kw * p.Cin * p.Cout * 4;
-  const bool vec_ok = (p.Cin % 4 == 0) && (p.mode == 1 || p.Cout % 4 == 0);
-  const bool fast = vec_ok && a_bytes < 0x7FFF0000LL && w_bytes < 0x7FFF0000LL && Mtot * p.Cout * 4 < 0x7FFF0000LL && p.kh * p.kw <= 32 &&
-                    (p.a_scale == nullptr || !p.aff_spatial || (p.aff_mask + 1) == p.Hin * p.Win * p.Cin);
-  if (p.Wbf != nullptr && fast && Mtot >= 4096 && Mtot < (1LL << 24) && Mtot * p.Cout * 4 < 0x7FFF0000LL && p.Cin % 32 == 0) return veex_launch_gather_gemm_bf16(p, mtiles, st);
+  const bool fast = gg_fast_ok(p);
+  if (gg_bf16_dispatch(p, fast)) return veex_launch_gather_gemm_bf16(p, mtiles, st);
+  if (p.Out == nullptr) { veex_set_error("gather_gemm: null output (only the bf16 engine can write the bf16 copy alone)"); return -1; }
   if (bm == 64 && fast && veex_env_int("VEEX_GGV3", 1) && veex_gg_v3_ok(p)) return veex_launch_gather_gemm_v3(p, mtiles, st);
   if (bm == 128 && bn == 128 && fast) return gg_launch_cfg<128, 128>(p, mtiles, true, st);
   if (bm == 128 && bn == 64 && fast) return gg_launch_cfg<128, 64>(p, mtiles, true, st);

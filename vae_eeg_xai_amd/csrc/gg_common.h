@@ -131,7 +131,8 @@ __device__ __forceinline__ void gg_epilogue_b(const GGParams& p, f32x16 (&acc)[B
   float* outp = p.Out;
   if (p.epi == VEEX_EPI_RAW) outp += (long long)kz * p.slab_stride;
   const unsigned out_bytes = (unsigned)p.Nb * p.Hout * p.Wout * p.Cout * 4u;
-  const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc(outp, 0, (int)out_bytes, 0x00020000);
+  // Out == nullptr (bf16 engine, only the bf16 copy is consumed): zero records, every fp32 store is dropped
+  const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc(outp, 0, p.Out != nullptr ? (int)out_bytes : 0, 0x00020000);
   const bool has_bf = (p.epi != VEEX_EPI_RAW) && (p.OutBf != nullptr);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(has_bf ? p.OutBf : static_cast<void*>(outp), 0,
                                                                       has_bf ? (int)(out_bytes >> 1) : 0, 0x00020000);

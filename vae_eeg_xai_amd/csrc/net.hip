@@ -689,6 +689,39 @@ static int run_wgrad(Ctx& c, WGParams& p, float* dW) {
   return veex_slab_sum(slab, s.nsplit, n, n, dW, nullptr, 1, 0, st);
 }
 
+// The two GEMMs that consume d(pre-activation) of decoder layer i: its weight gradient and its input gradient
+static void deconv_wgrad_desc(Ctx& c, int i, WGParams& w) {
+  const VeexNet* n = c.n;
+  const Plan& P = c.plan;
+  const ConvLayer& prod = (i == 0) ? n->ddense : n->dc[i - 1];
+  wg_desc_deconv(n, i, c.B, w);   // big = d(pre-act) of this layer, small = its input (with the producer's BN)
+  w.Big = c.ws + P.d_dc[i]; w.Small = (i == 0) ? c.ws + P.act_dd : c.ws + P.act_dc[i - 1];
+  w.BigBf = bfp(c, P.bf_d_dc[i]); w.SmallBf = (i == 0) ? bfp(c, P.bf_act_dd) : bfp(c, P.bf_act_dc[i - 1]);
+  w.s_scale = c.scale(prod.bn); w.s_shift = c.shift(prod.bn); w.s_aff_mask = prod.bnC - 1; w.s_aff_spatial = (i == 0);
+}
+static void deconv_dgrad_desc(Ctx& c, int i, GGParams& p) {
+  const VeexNet* n = c.n;
+  const Plan& P = c.plan;
+  const ConvLayer& l = n->dc[i];
+  memset(&p, 0, sizeof(p));
+  p.A = c.ws + P.d_dc[i]; p.W = c.P + l.w; p.Wbf = packed_w(c, i + 2, 0);
+  p.Abf = bfp(c, P.bf_d_dc[i]); p.OutBf = (i > 0) ? bfp(c, P.bf_d_dc[i - 1]) : nullptr;
+  p.Nb = c.B; p.Hin = p.Win = l.Hout; p.Cin = l.Cout; p.Hout = p.Wout = l.Hin; p.Cout = l.Cin;
+  p.kh = p.kw = l.k; p.stride = l.stride; p.pb = l.pb; p.mode = 0;
+}
+// bf16 engine: true when both of them read only the bf16 copy, so that the producer need not write the fp32 one
+// (372 MB less to write per step at batch 512)
+static bool dpre_dc_f32_unused(Ctx& c, int i) {
+  if (c.n->compute != VEEX_COMPUTE_BF16 || !veex_env_int("VEEX_BF_SKIPF32", 1)) return false;
+  WGParams w; deconv_wgrad_desc(c, i, w);
+  const SplitPlan s = wgrad_split(w);
+  w.nsplit = s.nsplit; w.rows_per_split = s.per;
+  if (!veex_wgrad_bf16c_ok(w)) return false;
+  GGParams p; deconv_dgrad_desc(c, i, p);
+  p.epi = (i > 0) ? VEEX_EPI_BWD : VEEX_EPI_FWD;
+  return veex_gg_bf16_only(p) >= 1;
+}
+
 static float* take_partials(Ctx& c, long long nfloats) {
   if (c.part_cur + nfloats > c.plan.partials_n) { veex_set_error("internal: partials scratch too small"); return nullptr; }
   float* p = c.ws + c.plan.partials + c.part_cur;
@@ -716,10 +749,12 @@ static int flush_colsum(Ctx& c) {
 }
 
 // dgrad GEMM with BN/ReLU-backward epilogue + finalisation of the producing layer's bias/gamma/beta grads
-static int dgrad_bwd(Ctx& c, GGParams& p, const ConvLayer& prod, const float* aux, float* dpre, float* G, int want_param_grads) {
+static int dgrad_bwd(Ctx& c, GGParams& p, const ConvLayer& prod, const float* aux, float* dpre, float* G, int want_param_grads,
+                     bool f32_unused = false) {
   const VeexNet* n = c.n;
   p.Out = dpre; p.aux = aux; p.epi = VEEX_EPI_BWD; p.relu = 1; p.nsplit = 1;
   if (prod.bn >= 0) { p.e_scale = c.scale(prod.bn); p.epi_cmask = prod.bnC - 1; }
+  if (f32_unused && veex_gg_bf16_only(p) == 2) p.Out = nullptr;   // only the bf16 copy of this gradient is read
   GGParams q = p;
   const int mt = veex_gg_m_tiles(q);
   p.partials = nullptr;
@@ -894,30 +929,23 @@ extern "C" int veex_net_train_fwd_bwd(const VeexNet* n, const float* params, con
     const ConvLayer& l5 = n->dc[4];
     float* d6 = take_partials(c, (long long)B * 448);   // rows 0-3 dW6 partials, rows 4-6 the three column sums
     if (d6 == nullptr) return VEEX_ENOMEM;
+    float* d5 = (bfp(c, P.bf_d_dc[4]) != nullptr && dpre_dc_f32_unused(c, 4)) ? nullptr : ws + P.d_dc[4];
     TRY(veex_deconv6_bwd_bf16(ws + P.dlogit, ws + P.act_dc[4], c.scale(l5.bn), c.shift(l5.bn), c.P + n->dc[5].w,
-                              ws + P.d_dc[4], bfp(c, P.bf_d_dc[4]), d6, B, st));
+                              d5, bfp(c, P.bf_d_dc[4]), d6, B, st));
     TRY(veex_slab_sum(d6, B, 448, 256, G + n->dc[5].w, nullptr, 1, 0, st));
     TRY(defer_colsum(c, d6 + 256, B, 448, 64, 64, c.scale(l5.bn), c.mean(l5.bn), c.rstd(l5.bn), G + l5.b,
                      G + n->gamma_off + l5.bn, G + n->beta_off + l5.bn));
   }
   for (int i = 4; i >= 0; --i) {
     const ConvLayer& l = n->dc[i];
-    const float* in = (i == 0) ? ws + P.act_dd : ws + P.act_dc[i - 1];
     const ConvLayer& prod = (i == 0) ? n->ddense : n->dc[i - 1];
-    {  // dW: big = d(pre-act) of this layer, small = its input (with the producer's BN)
-      WGParams w; wg_desc_deconv(n, i, B, w);
-      w.Big = ws + P.d_dc[i]; w.Small = in;
-      w.BigBf = bfp(c, P.bf_d_dc[i]); w.SmallBf = (i == 0) ? bfp(c, P.bf_act_dd) : bfp(c, P.bf_act_dc[i - 1]);
-      w.s_scale = c.scale(prod.bn); w.s_shift = c.shift(prod.bn); w.s_aff_mask = prod.bnC - 1; w.s_aff_spatial = (i == 0);
+    {
+      WGParams w; deconv_wgrad_desc(c, i, w);
       TRY(run_wgrad(c, w, G + l.w));
     }
-    GGParams p; memset(&p, 0, sizeof(p));
-    p.A = ws + P.d_dc[i]; p.W = c.P + l.w; p.Wbf = packed_w(c, i + 2, 0);
-    p.Abf = bfp(c, P.bf_d_dc[i]); p.OutBf = (i > 0) ? bfp(c, P.bf_d_dc[i - 1]) : nullptr;
-    p.Nb = B; p.Hin = p.Win = l.Hout; p.Cin = l.Cout; p.Hout = p.Wout = l.Hin; p.Cout = l.Cin;
-    p.kh = p.kw = l.k; p.stride = l.stride; p.pb = l.pb; p.mode = 0;
+    GGParams p; deconv_dgrad_desc(c, i, p);
     if (i > 0) {
-      TRY(dgrad_bwd(c, p, prod, ws + P.act_dc[i - 1], ws + P.d_dc[i - 1], G, 1));
+      TRY(dgrad_bwd(c, p, prod, ws + P.act_dc[i - 1], ws + P.d_dc[i - 1], G, 1, dpre_dc_f32_unused(c, i - 1)));
     } else {
       // BatchNorm of dec.dense runs over the flattened 4096 features: plain dgrad, then row-wise BN/ReLU backward
       p.Out = ws + P.g_dd; p.epi = VEEX_EPI_FWD; p.relu = 0; p.bias = nullptr; p.nsplit = 1;

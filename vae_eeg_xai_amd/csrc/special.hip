@@ -303,7 +303,7 @@ __global__ __launch_bounds__(D6_THREADS) void deconv6_bwd_kernel(
     o.z = (a.z > 0.f) ? g.z : 0.f; o.w = (a.w > 0.f) ? g.w : 0.f;
     acc[6].x += o.x; acc[6].y += o.y; acc[6].z += o.z; acc[6].w += o.w;
     o.x *= sc.x; o.y *= sc.y; o.z *= sc.z; o.w *= sc.w;
-    *reinterpret_cast<float4*>(dst + pix * NCH + 4 * cq) = o;
+    if (dpre5 != nullptr) *reinterpret_cast<float4*>(dst + pix * NCH + 4 * cq) = o;
     if (dpre5_bf != nullptr) {
       bf16x4_t h;
       h[0] = (__bf16)o.x; h[1] = (__bf16)o.y; h[2] = (__bf16)o.z; h[3] = (__bf16)o.w;
@@ -726,6 +726,7 @@ int veex_deconv6_bwd(const float* dlogit, const float* a5, const float* scale, c
 
 int veex_deconv6_bwd_bf16(const float* dlogit, const float* a5, const float* scale, const float* shift, const float* W6,
                           float* dpre5, void* dpre5_bf16, float* slab, int B, hipStream_t st) {
+  if (dpre5 == nullptr && dpre5_bf16 == nullptr) { veex_set_error("deconv6_bwd: no output buffer"); return -1; }
   hipLaunchKernelGGL(deconv6_bwd_kernel, dim3(B), dim3(D6_THREADS), 0, st, dlogit, a5, scale, shift, W6, dpre5, slab,
                      reinterpret_cast<__bf16*>(dpre5_bf16));
   VEEX_CHECK_LAUNCH();

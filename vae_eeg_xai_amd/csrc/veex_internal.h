@@ -102,6 +102,8 @@ int veex_launch_wgrad(const WGParams& p, hipStream_t st);
 int veex_gg_m_tiles(GGParams& p);   // fills phase tables; returns total m tiles for the chosen config
 int veex_gg_m_tiles_bm(GGParams& p, int bm);   // same for a given tile height (64: upper bound for sizing)
 int veex_gg_bm(const GGParams& p);
+int veex_gg_bf16_only(const GGParams& p);   // gather_gemm.hip: 0 no, 1 reads only the bf16 A copy, 2 and may write the bf16 copy alone
+int veex_wgrad_bf16c_ok(const WGParams& p);  // wgrad_gemm_bf16.hip: the copy kernel (reads only the two bf16 copies) takes it
 int veex_wg_tiles(const WGParams& p, int* bm, int* bn);
 int veex_wgrad_bf16_ok(const WGParams& p);                       // wgrad_gemm_bf16.hip
 #define VEEX_WG3_MAX_ROWS 3072                                    // rows_per_split the LDS row table of wgrad_gemm_v3.hip holds
