@@ -111,9 +111,9 @@ def attribution_bench(net, x_all, world, iters=8, warmup=2):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if world > 1:
+            from vae_eeg_xai_amd import dist as vdist
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            dt = float(vdist.allreduce_max_(t).item())
         maps = iters * B * len(units) * world
         flop = 2.0 * (ATTR_MACS_FWD * iters * B + ATTR_MACS_BWD * iters * B * len(units)) * world
         out[label] = {"maps_per_s": maps / dt, "ms_per_batch": 1e3 * dt / iters, "tflops": flop / dt / 1e12}
@@ -145,33 +145,49 @@ def main():
         if world == 1 and args.gpus > 1:
             print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
             sys.exit(2)
+    # rehearsal on a one-GPU box: VEEX_DIST_BACKEND=gloo VEEX_DIST_ONE_GPU=1 puts every rank on cuda:0 and moves the
+    # collectives through the host (checks the N > 1 control flow, not its speed)
+    backend = os.environ.get("VEEX_DIST_BACKEND", "nccl")
+    if os.environ.get("VEEX_DIST_ONE_GPU", "0") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
 
     from vae_eeg_xai_amd.net import Net
     from vae_eeg_xai_amd import roofline as rl
+    from vae_eeg_xai_amd import dist as vdist
+
+    def note(msg):     # progress on stderr (stdout carries only the JSON line)
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
     B = args.batch
+    note(f"world {world}, backend {backend if world > 1 else '-'}, batch {B}/GPU, {args.dtype}")
     net = Net(LATENT, "vae", compute=args.dtype)
     net.init_weights(seed=42)                      # same weights on every rank
     # weak scaling: every rank holds its own shard of the synthetic set (N_TRAIN / world maps)
     n_local = max(B, (N_TRAIN // world) // B * B)
     x_all = torch.from_numpy(synth(n_local, seed=1234 + rank)).cuda()
     nb = n_local // B
+    note(f"{n_local} synthetic maps resident per rank")
 
     def step(i):
         xb = x_all[(i % nb) * B:(i % nb + 1) * B]
         # Philox epsilon keyed by the global sample index -> independent of the world size
         net.train_fwd_bwd(xb, None, first_sample=(i * world + rank) * B)
         if world > 1:
-            dist.all_reduce(net.grads)             # one RCCL all-reduce: grads + 3 loss scalars
+            vdist.allreduce_sum_(net.grads)        # one RCCL all-reduce: grads + 3 loss scalars
         net.adam_step(LR, 1.0 / world)
 
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    note("warm-up done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -185,9 +201,9 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = float(vdist.allreduce_max_(t).item())
     loss = float(net.grads[net.n_params].item()) / world
+    note(f"{args.steps} steps timed: {1e3 * dt / args.steps:.3f} ms/step")
     attr = None if args.no_attribution else attribution_bench(net, x_all, world)
 
     if rank == 0:
@@ -213,6 +229,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()          # rank 0 may still have been measuring its roofline: leave together
         dist.destroy_process_group()
 
 

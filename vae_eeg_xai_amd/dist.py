@@ -24,11 +24,30 @@ def shard_range(n: int, r: int, world: int):
     return lo, lo + base + (1 if r < rem else 0)
 
 
+def _all_reduce_(t: torch.Tensor, op) -> torch.Tensor:
+    """dist.all_reduce in place; a device tensor under a host-only backend (gloo rehearsals of the
+    N > 1 path on a one-GPU box) is staged through host memory."""
+    if t.is_cuda and dist.get_backend() != "nccl":
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
 def allreduce_sum_(flat: torch.Tensor) -> torch.Tensor:
     """In-place SUM all-reduce of a flat fp32 buffer (no-op for a single process)."""
     if world_size() > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        _all_reduce_(flat, dist.ReduceOp.SUM)
     return flat
+
+
+def allreduce_max_(t: torch.Tensor) -> torch.Tensor:
+    """In-place MAX all-reduce (the max-over-ranks wall time of bench.py)."""
+    if world_size() > 1:
+        _all_reduce_(t, dist.ReduceOp.MAX)
+    return t
 
 
 def global_first_sample(step: int, r: int, world: int, local_batch: int) -> int:
