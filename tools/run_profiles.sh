@@ -14,4 +14,10 @@ timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/t
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python tools/prof_gemms.py 512 2 > $O/pmc_fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python tools/prof_gemms.py 512 2 > $O/pmc_write.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- python tools/prof_gemms.py 512 2 > $O/pmc_sq.log 2>&1
+# one train step with the side stream off: per-kernel times that no concurrent kernel stretches (fp32, bf16)
+bash tools/prof_seq.sh $R/seq_f32 > $O/seq_f32.txt 2>&1
+bash tools/prof_seq.sh $R/seq_bf16 --dtype bf16 > $O/seq_bf16.txt 2>&1
+# attribution only (batch 4096: 3 x top-1 unit, 3 x all 28 units)
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/attr -- python tools/prof_attr.py > $O/attr.log 2>&1
+timeout -k 10 60 tools/micro/mfma_issue > $O/micro_mfma_issue.txt 2>&1
 echo PROFILES_DONE

@@ -22,6 +22,36 @@ with open(f"{dst}/{R}_kernel_stats.txt", "w") as f:
         f.write(f"{r['Name'][:100]:100s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs']) / 1e3:9.1f} pct={float(r['Percentage']):6.2f}\n")
 
 
+# the same trace split by launch shape: one kernel name serves several layers, the grid tells them apart
+# (gather_gemm_v3_kernel<true, 1> with 11552 x 256 threads is dec.deconv4 forward at batch 512, bench.py's `roofline` kernel)
+kt = newest(f"{src}/trace/*/*kernel_trace.csv")
+by = collections.OrderedDict()
+for r in csv.DictReader(open(kt)):
+    if "gather_gemm" in r["Kernel_Name"] or "wgrad_" in r["Kernel_Name"]:
+        by.setdefault((r["Kernel_Name"][:60], int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])), []).append(
+            (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+with open(f"{dst}/{R}_kernel_stats_by_launch.txt", "w") as f:
+    f.write("same rocprofv3 --kernel-trace run, MFMA launches grouped by (kernel, workgroups): with the side stream on, a launch "
+            "that shares the GPU with a weight-gradient GEMM is stretched; see *_seq_f32.txt for undisturbed times\n")
+    for (name, blocks), v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+        f.write(f"{name:60s} workgroups={blocks:6d} calls={len(v):4d} avg_us={sum(v) / len(v):8.1f} min_us={min(v):8.1f}\n")
+
+for extra, hdr in (("seq_f32.txt", "fp32"), ("seq_bf16.txt", "bf16")):
+    if os.path.exists(f"{src}/{extra}"):
+        with open(f"{dst}/{R}_{extra}", "w") as f:
+            f.write(f"VEEX_OVERLAP=0 rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 ... ({hdr}; "
+                    "side stream off, so no kernel's duration is stretched by a concurrent one; tools/prof_seq.sh)\n")
+            f.write(open(f"{src}/{extra}").read())
+if os.path.exists(f"{src}/micro_mfma_issue.txt"):
+    shutil.copy(f"{src}/micro_mfma_issue.txt", f"{dst}/{R}_micro_mfma_issue.txt")
+att = glob.glob(f"{src}/attr/*/*kernel_stats.csv")
+if att:
+    with open(f"{dst}/{R}_attr_kernel_stats.txt", "w") as f:
+        f.write("rocprofv3 --kernel-trace --stats -- python tools/prof_attr.py   (attribution, batch 4096: 3 x [unit 3], 3 x [all 28 units])\n")
+        for r in csv.DictReader(open(max(att, key=os.path.getmtime))):
+            f.write(f"{r['Name'][:100]:100s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs']) / 1e3:9.1f} pct={float(r['Percentage']):6.2f}\n")
+
+
 def per_dispatch(path):
     d = collections.OrderedDict()
     for r in csv.DictReader(open(path)):
