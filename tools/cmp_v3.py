@@ -33,8 +33,9 @@ def run(name, mode, N, Hin, Cin, Hout, Cout, k, s, pb, aff=0, epi=0, nsplit=1):
         tmp = torch.empty(1, device="cuda"); d.out = tmp.data_ptr()
         mt = lib.veex_gather_gemm_m_tiles(C.byref(d))
     res = []
-    for v in ("0", "1"):
+    for v, ro in (("0", "0"), ("1", "0"), ("1", "1")):
         os.environ["VEEX_GGV3"] = v
+        os.environ["VEEX_ROWORD"] = ro   # 1: tiles over (image row, sample, column); skips taps a whole tile pads
         out = torch.full((max(nsplit, 1), N, Hout, Hout, Cout), 7.0, device="cuda")
         d.out = out.data_ptr()
         part = None
@@ -43,12 +44,15 @@ def run(name, mode, N, Hin, Cin, Hout, Cout, k, s, pb, aff=0, epi=0, nsplit=1):
         check(lib.veex_gather_gemm(C.byref(d), _lib.current_stream()), name)
         torch.cuda.synchronize()
         res.append((out.clone(), None if part is None else part.clone()))
-    a, b = res[0][0], res[1][0]
-    e = (a - b).abs().max().item() / max(a.abs().max().item(), 1e-30)
-    msg = f"{name:34s} out rel diff {e:.3e}"
+    a, b, c = res[0][0], res[1][0], res[2][0]
+    den = max(a.abs().max().item(), 1e-30)
+    msg = f"{name:34s} out rel diff {(a - b).abs().max().item() / den:.3e} / row order 1: {(a - c).abs().max().item() / den:.3e}"
     if epi == 1:
-        pa, pb_ = res[0][1], res[1][1]
-        msg += f"   partials rel diff {(pa - pb_).abs().max().item() / max(pa.abs().max().item(), 1e-30):.3e}"
+        pa, pb_, pc = res[0][1], res[1][1], res[2][1]
+        pden = max(pa.abs().max().item(), 1e-30)
+        ta, tc = pa.view(mt, 3, Cout).sum(0), pc.view(mt, 3, Cout).sum(0)   # tiles hold other rows: compare the totals
+        msg += (f"   partials rel diff {(pa - pb_).abs().max().item() / pden:.3e}"
+                f" / column totals, row order 1: {(ta - tc).abs().max().item() / max(ta.abs().max().item(), 1e-30):.3e}")
     print(msg)
 
 run("5x5 valid Cout=128 fwd", 0, 4, 5, 256, 1, 128, 5, 1, 0, aff=1)

@@ -13,7 +13,11 @@
 //     offset, which sends it out of range: the load returns zeros.  2 VALU per A load, 0 per B load;
 //   * the producer BatchNorm is 4 v_fma: its shift is fetched through the same masked offset, so a
 //     padding pixel gets shift 0 and stays exactly 0 without a select;
-//   * chunk -> (tap, channel slice) is carried incrementally in SGPRs.
+//   * chunk -> (tap, channel slice) is carried incrementally in SGPRs (scalar instructions are free beside MFMAs);
+//   * taps that are padding for EVERY row of a tile are not executed at all: the rows of a tile run over
+//     (image row, sample, column) (GGParams::row_order = 1), so a tile shares its image row and with it the
+//     vertical validity of the taps; the valid-tap set of the tile (OR over its rows, one LDS word) is walked with
+//     s_ff1.  Skipped products are exact zeros, so the result is bit-identical.
 // Constraints (else the general kernel runs): Cin % 16 == 0, operands < 2 GiB, <= 31 taps.
 // Same data layout, epilogues and results as gather_gemm_kernel (k order inside a chunk included).
 #include "gg_common.h"
@@ -45,6 +49,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   float* As = smem;
   float* Bs = smem + 2 * A_ELEMS;
   unsigned* s_offb = reinterpret_cast<unsigned*>(Bs + 2 * B_ELEMS);   // [BM] output row byte offsets
+  unsigned* s_tmk = s_offb + BM;                                      // valid-tap set of the tile
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -73,19 +78,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   }
   const int cpt = p.Cin / BK;
   const int ntaps = nky * nkx;
-  const int nchunks = ntaps * cpt;
-  const int c_begin = kz * p.chunks_per_split;
-  const int c_end = min(nchunks, c_begin + p.chunks_per_split);
-  const int HWp = Hp * Wp;
-  const float invHWp = 1.0f / (float)HWp, invWp = 1.0f / (float)Wp;   // rows < 2^24 (veex_gg_v3_ok)
+  // row m of the phase -> (sample n, phase row j, phase column i): (n, j, i) order, or (j, n, i) with row_order 1
+  const int D1 = p.row_order ? p.Nb * Wp : Hp * Wp;
+  const float invD1 = 1.0f / (float)D1, invWp = 1.0f / (float)Wp;   // rows < 2^24 (veex_gg_v3_ok)
+  auto row_nji = [&](int m, int& n, int& j, int& i) {
+    int a, rem, b;
+    g3_divmod(m, D1, invD1, a, rem);
+    g3_divmod(rem, Wp, invWp, b, i);
+    n = p.row_order ? b : a;
+    j = p.row_order ? a : b;
+  };
 
+  if (tid == 0) *s_tmk = 0u;
   if (tid < BM) {
     const int m = m0 + tid;
     unsigned off = 0x80000000u;   // + any column offset stays out of range: the store is dropped
     if (m < Mph) {
-      int n, rem, j, i;
-      g3_divmod(m, HWp, invHWp, n, rem);
-      g3_divmod(rem, Wp, invWp, j, i);
+      int n, j, i;
+      row_nji(m, n, j, i);
       off = (unsigned)(((n * p.Hout + ostep * j + oy0) * p.Wout + ostep * i + ox0) * p.Cout) * 4u;
     }
     s_offb[tid] = off;
@@ -115,9 +125,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   {
     const int m = m0 + lr;
     if (m < Mph) {
-      int n, rem, j, ii;
-      g3_divmod(m, HWp, invHWp, n, rem);
-      g3_divmod(rem, Wp, invWp, j, ii);
+      int n, j, ii;
+      row_nji(m, n, j, ii);
       const int oy = ostep * j + oy0, ox = ostep * ii + ox0;
       int by, bx;   // input pixel read by phase tap (0,0)
       if (MODE1) { by = (oy + p.pb - kys) >> (p.stride - 1); bx = (ox + p.pb - kxs) >> (p.stride - 1); }
@@ -138,6 +147,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
       a_inv = ~mk;   // bits >= ntaps (bit 31 included: "chunk past the end") stay set
     }
   }
+  // valid-tap set of the tile: split-K launches keep every tap (their chunk ranges are planned on the host)
+  __syncthreads();
+  if (q == 0 && ~a_inv != 0u) atomicOr(s_tmk, ~a_inv);
+  __syncthreads();
+  const unsigned all_taps = (ntaps >= 32) ? 0xFFFFFFFFu : ((1u << ntaps) - 1u);
+  const unsigned tile_mk = (p.nsplit > 1) ? all_taps : (unsigned)__builtin_amdgcn_readfirstlane((int)(*s_tmk & all_taps));
+  const int nvalid = __builtin_popcount(tile_mk);
   // ---- B loader ----
   unsigned b_voff;
   if (MODE1) {   // [tap][Cout][Cin]: row n0 + tid/4, quad q along Cin
@@ -152,23 +168,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 
   struct Stage { float4 ra, rb, rsc, rsh; };
 
-  // running (tap, channel slice) of the next chunk to load; chunks are loaded strictly in order
+  const int nchunks = nvalid * cpt;
+  const int c_begin = kz * p.chunks_per_split;
+  const int c_end = min(nchunks, c_begin + p.chunks_per_split);
+  // running (tap, channel slice) of the next chunk to load; chunks are loaded strictly in order: per channel slice
+  // the set bits of tile_mk in ascending order
   int it_c = c_begin;
-  int it_cc = c_begin / ntaps;
-  int it_tapi = c_begin - it_cc * ntaps;
-  int it_ia = it_tapi / nkx, it_ib = it_tapi - it_ia * nkx;
+  int it_cc = (nvalid > 0) ? c_begin / nvalid : 0;
+  unsigned it_bits = tile_mk;
+  for (int k = c_begin - it_cc * nvalid; k > 0; --k) it_bits &= it_bits - 1u;   // (split-K: tile_mk is the full set)
+  const int inv_nkx = 65536 / nkx + 1;   // tapi / nkx for tapi < 32
 
   auto load_chunk = [&](Stage& st) {
     const bool cvalid = it_c < c_end;
-    const int tapi = cvalid ? it_tapi : 31;     // bit 31 of a_inv is always set: zeros
-    const int ia = it_ia, ib = it_ib;
+    const int tapi = cvalid ? __builtin_ctz(it_bits | 0x80000000u) : 31;     // bit 31 of a_inv is always set: zeros
+    const int ia = (tapi * inv_nkx) >> 16, ib = tapi - ia * nkx;
     const int ci0b = cvalid ? it_cc * (BK * 4) : 0;
     const int tap = cvalid ? (kys + kstep * ia) * p.kw + (kxs + kstep * ib) : 0;
     const int dpix = MODE1 ? ((nky - 1 - ia) * p.Win + (nkx - 1 - ib)) : (ia * p.Win + ib);
     const int delta = cvalid ? dpix * p.Cin * 4 + ci0b : 0;
-    ++it_c; ++it_tapi; ++it_ib;
-    if (it_ib == nkx) { it_ib = 0; ++it_ia; }
-    if (it_tapi == ntaps) { it_tapi = 0; it_ia = 0; it_ib = 0; ++it_cc; }
+    ++it_c;
+    it_bits &= it_bits - 1u;
+    if (it_bits == 0u) { it_bits = tile_mk; ++it_cc; }
 
     const unsigned m = (unsigned)__builtin_amdgcn_sbfe(a_inv, tapi, 1);   // 0 or 0xFFFFFFFF
     st.ra = bload4s(rA, a_voff | m, delta);
@@ -323,7 +344,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 
 template <bool MODE1>
 static void gg3_launch(const GGParams& p, int aff, dim3 grid, hipStream_t st) {
-  constexpr size_t lds = (2 * 64 * 20 + 2 * (MODE1 ? 64 * 20 : 16 * 68)) * sizeof(float) + 64 * sizeof(unsigned);
+  constexpr size_t lds = (2 * 64 * 20 + 2 * (MODE1 ? 64 * 20 : 16 * 68)) * sizeof(float) + (64 + 4) * sizeof(unsigned);
   if (aff == 0) hipLaunchKernelGGL((gather_gemm_v3_kernel<MODE1, 0>), grid, dim3(256), lds, st, p);
   else if (aff == 1) hipLaunchKernelGGL((gather_gemm_v3_kernel<MODE1, 1>), grid, dim3(256), lds, st, p);
   else hipLaunchKernelGGL((gather_gemm_v3_kernel<MODE1, 2>), grid, dim3(256), lds, st, p);
@@ -357,6 +378,10 @@ int veex_launch_gather_gemm_v3(GGParams& p, int mtiles, hipStream_t st) {
   p.remap = (xr < 0) ? (p.nphase == 1) : xr;
   p.gx = ntiles; p.gy = mtiles; p.gz = p.nsplit;
   dim3 grid((unsigned)ntiles * mtiles * p.nsplit, 1, 1);
+  // one image row per tile wherever a launch has vertically padded taps to skip (A/B at batch 512: -2...-8 % on
+  // those launches, +3 % on a launch without padding, whose tiles then only lose locality)
+  const bool vpad = (p.mode == 1) ? true : (p.pb > 0 || (p.Hout - 1) * p.stride + p.kh - 1 - p.pb >= p.Hin);
+  p.row_order = (p.kh > 1 && p.nsplit == 1 && vpad) ? veex_env_int("VEEX_ROWORD", 1) : 0;
   const int aff = (p.a_scale == nullptr) ? 0 : (p.aff_spatial ? 2 : 1);
   if (p.mode == 1) gg3_launch<true>(p, aff, grid, st);
   else gg3_launch<false>(p, aff, grid, st);

@@ -51,6 +51,7 @@ struct GGParams {
   const float* o_shift;
   int o_cmask;           // o_scale index = col & o_cmask
   int dbg;               // timing-only switches of the bf16 engine (VEEX_DBG; results are wrong when non-zero)
+  int row_order;         // lean fp32 kernel: 0 = tile rows run over (n, y, x), 1 = over (y, n, x) -- one image row per tile
 };
 
 // ---------------------------------------------------------------------------
