@@ -193,8 +193,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WGParams p) {
 // into the [channel][k] LDS tile.  K chunk = 64 rows: waves 0-1 stage Big (16 octets x 8 row groups),
 // waves 2-3 stage Small, every wave multiplies.  LDS rows are 64 bf16 + 8 pad = 144 B = 9 sixteen-byte
 // slots (odd): both the permuted-row writes (rho = e*(T/8) + octet) and the operand reads are
-// conflict-free.
+// conflict-free.  Row -> pixel address and tap validity come from a windowed LDS row table (512 rows, rebuilt
+// every 8 chunks; the wgrad_gemm_v3.hip idea): 3 VALU per 16-byte load instead of ~20 (the staging VALU work,
+// not the MFMAs, bounded this kernel).
 // ---------------------------------------------------------------------------
+#define WGBC_TABW 512   // rows per window of the row table (8 chunks)
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void wgrad_bf16c_kernel(const WGParams p) {
   constexpr int BK = 64, LDKH = BK + 8;
@@ -204,10 +207,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16c_kernel(const WGParams p) {
   constexpr int OM = BM / 8, ON = BN / 8;            // channel octets per tile
   constexpr int A_ELEMS = BM * LDKH, B_ELEMS = BN * LDKH;
   static_assert(BM == 128 && (BN == 128 || BN == 64), "waves 0-1 stage A, waves 2-3 stage B");
+  static_assert(WGBC_TABW % BK == 0, "a chunk never straddles two table windows");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* As = reinterpret_cast<__bf16*>(smem_raw);      // [2][BM][72]
   __bf16* Bs = As + 2 * A_ELEMS;                         // [2][BN][72]
+  int2* tab = reinterpret_cast<int2*>(Bs + 2 * B_ELEMS); // [WGBC_TABW] (byte offset of the row's pixel in Big, ~valid taps)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -228,18 +233,23 @@ __global__ __launch_bounds__(256) void wgrad_bf16c_kernel(const WGParams p) {
   const int oct = u % OT, rg = u / OT;                   // channel octet, 8-row group
   const bool active = rg < 8;                            // BN = 64: wave 3 has nothing to stage
   const int ch0 = (isA ? m0 : n0) + 8 * oct;
-  int C, H, W, str, pb, ky = 0, kx = 0, cch;
-  bool ch_ok;
+  // A (Big) threads: the tap and channel of the octet are fixed, the pixel of a row comes from the row table:
+  //   address = tab[row].x + a_const, forced out of range (-> zeros) by the row's inverted tap mask
+  // B (Small) threads: rows are linear in memory: a constant per-row offset + the chunk's base in the scalar offset
+  int atap = 31, a_const = 0;      // bit 31 of every mask is set: zeros
+  unsigned b_voff[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) b_voff[k] = VEEX_OOB;
   if (isA) {
-    C = p.Cb; H = p.Hb; W = p.Wb; str = p.stride; pb = p.pb;
-    ch_ok = active && ch0 < p.M;
-    const int tap = ch0 / p.Cb;
-    cch = ch0 - tap * p.Cb;
-    ky = tap / p.kw; kx = tap - ky * p.kw;
-  } else {
-    C = p.Cs; H = p.Hs; W = p.Ws; str = 1; pb = 0;
-    ch_ok = active && ch0 < p.Cs;
-    cch = ch0;
+    if (active && ch0 < p.M) {
+      atap = ch0 / p.Cb;
+      const int cch = ch0 - atap * p.Cb;
+      const int ky = atap / p.kw, kx = atap - ky * p.kw;
+      a_const = ((ky * p.Wb + kx) * p.Cb + cch) * 2;
+    }
+  } else if (active && ch0 < p.Cs) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) b_voff[k] = (unsigned)(((8 * rg + k) * p.Cs + ch0) * 2);
   }
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(isA ? p.BigBf : p.SmallBf), 0,
@@ -250,28 +260,45 @@ __global__ __launch_bounds__(256) void wgrad_bf16c_kernel(const WGParams p) {
   const int lds_estride = OT * LDKH;
   const int lds_elems = isA ? A_ELEMS : B_ELEMS;
 
+  // window w of the row table: rows r_begin + w*TABW ... ; rows past the split read zeros for every tap
+  auto build_window = [&](int w) {
+    for (int t = tid; t < WGBC_TABW; t += 256) {
+      const int r = r_begin + w * WGBC_TABW + t;
+      int off = 0;
+      unsigned inv = 0xFFFFFFFFu;
+      if (r < r_end) {
+        int q1 = (int)((float)r * invHWs); int m1 = r - q1 * HWs;
+        if (m1 < 0) { q1 -= 1; m1 += HWs; }
+        if (m1 >= HWs) { q1 += 1; m1 -= HWs; }
+        int q2 = (int)((float)m1 * invWs); int m2 = m1 - q2 * p.Ws;
+        if (m2 < 0) { q2 -= 1; m2 += p.Ws; }
+        if (m2 >= p.Ws) { q2 += 1; m2 -= p.Ws; }
+        const int y0 = p.stride * q2 - p.pb, x0 = p.stride * m2 - p.pb;
+        off = (((q1 * p.Hb + y0) * p.Wb + x0) * p.Cb) * 2;   // may be "virtual" (negative) at the border
+        unsigned xb = 0u, mk = 0u;
+        for (int kx = 0; kx < p.kw; ++kx) if (x0 + kx >= 0 && x0 + kx < p.Wb) xb |= 1u << kx;
+        for (int ky = 0; ky < p.kh; ++ky) if (y0 + ky >= 0 && y0 + ky < p.Hb) mk |= xb << (ky * p.kw);
+        inv = ~mk;
+      }
+      tab[t] = make_int2(off, (int)inv);
+    }
+  };
+
   v4u ra[8];
 
   auto load_chunk = [&](int c) {
-    const int r0 = r_begin + c * BK + 8 * rg;
-    int n, py, px;
-    {
-      int q1 = (int)((float)r0 * invHWs); int m1 = r0 - q1 * HWs;
-      if (m1 < 0) { q1 -= 1; m1 += HWs; }
-      if (m1 >= HWs) { q1 += 1; m1 -= HWs; }
-      n = q1;
-      int q2 = (int)((float)m1 * invWs); int m2 = m1 - q2 * p.Ws;
-      if (m2 < 0) { q2 -= 1; m2 += p.Ws; }
-      if (m2 >= p.Ws) { q2 += 1; m2 -= p.Ws; }
-      py = q2; px = m2;
-    }
+    if (isA) {
+      const int2* tp = tab + ((c * BK) & (WGBC_TABW - 1)) + 8 * rg;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int by = str * py + ky - pb, bx = str * px + kx - pb;
-      const bool ok = ch_ok && (r0 + k) < r_end && by >= 0 && by < H && bx >= 0 && bx < W;
-      ra[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? (unsigned)((((n * H + by) * W + bx) * C + cch) * 2) : VEEX_OOB, 0, 0);
-      px += 1;
-      if (px == p.Ws) { px = 0; py += 1; if (py == p.Hs) { py = 0; n += 1; } }
+      for (int k = 0; k < 8; ++k) {
+        const int2 e = tp[k];
+        const unsigned m = (unsigned)__builtin_amdgcn_sbfe(e.y, atap, 1);   // 0 or 0xFFFFFFFF
+        ra[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)(e.x + a_const) | m, 0, 0);
+      }
+    } else {
+      const int soff = (r_begin + c * BK) * p.Cs * 2;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) ra[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, b_voff[k], soff, 0);
     }
   };
 
@@ -301,12 +328,18 @@ __global__ __launch_bounds__(256) void wgrad_bf16c_kernel(const WGParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  build_window(0);
+  __syncthreads();
   load_chunk(0);
   store_chunk(0);
   __syncthreads();
 
   for (int c = 0; c < nchunks; ++c) {
     const int cur = c & 1;
+    if (((c + 1) & (WGBC_TABW / BK - 1)) == 0) {   // the loads of chunk c were issued an iteration ago
+      build_window((c + 1) / (WGBC_TABW / BK));
+      __syncthreads();
+    }
     load_chunk(c + 1);  // past the end: out-of-range offsets -> zeros, never read
     const __bf16* as = As + cur * A_ELEMS + (wm * WTM + l31) * LDKH + 8 * lh;
     const __bf16* bs = Bs + cur * B_ELEMS + (wn * WTN + l31) * LDKH + 8 * lh;
@@ -352,7 +385,7 @@ static int wgbc_launch(const WGParams& pin, hipStream_t st) {
   p.gx = (p.M + BM - 1) / BM; p.gy = (p.Cs + BN - 1) / BN; p.gz = p.nsplit;
   p.remap = veex_env_int("VEEX_XCD_WG", 1);   // -7 %: the tap tiles of one row split share their rows of `big` in one L2
   dim3 grid((unsigned)p.gx * p.gy * p.gz, 1, 1);
-  constexpr size_t lds = 2 * (BM + BN) * 72 * 2;
+  constexpr size_t lds = 2 * (BM + BN) * 72 * 2 + WGBC_TABW * sizeof(int2);
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16c_kernel<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
