@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WGParams p) {
 // ---------------------------------------------------------------------------
 #define WGBC_TABW 512   // rows per window of the row table (8 chunks)
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void wgrad_bf16c_kernel(const WGParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_bf16c_kernel(const WGParams p) {
   constexpr int BK = 64, LDKH = BK + 8;
   constexpr int WM = 2, WN = 2;
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -251,9 +251,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16c_kernel(const WGParams p) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) b_voff[k] = (unsigned)(((8 * rg + k) * p.Cs + ch0) * 2);
   }
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void*>(isA ? p.BigBf : p.SmallBf), 0,
-      (int)(isA ? (unsigned)p.Nb * p.Hb * p.Wb * p.Cb * 2u : (unsigned)p.R * p.Cs * 2u), 0x00020000);
+  // one resource per role, each built from kernel arguments only: a per-thread select of the two made the
+  // descriptor a VGPR value and every load a readfirstlane "waterfall" loop (~12 extra instructions per load)
+  const __amdgpu_buffer_rsrc_t rBig = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.BigBf), 0, (int)((unsigned)p.Nb * p.Hb * p.Wb * p.Cb * 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rSmall = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.SmallBf), 0, (int)((unsigned)p.R * p.Cs * 2u), 0x00020000);
   const int HWs = p.Hs * p.Ws;
   const float invHWs = 1.0f / (float)HWs, invWs = 1.0f / (float)p.Ws;
   __bf16* const lds_dst = (isA ? As : Bs) + oct * LDKH + 8 * rg;     // + buf*ELEMS + e*OT*LDKH
@@ -284,27 +287,34 @@ __global__ __launch_bounds__(256) void wgrad_bf16c_kernel(const WGParams p) {
     }
   };
 
-  v4u ra[8];
+  struct Stage { v4u ra[8]; };
 
-  auto load_chunk = [&](int c) {
+  auto load_chunk = [&](Stage& sg, int c) {
+    v4u (&ra)[8] = sg.ra;
+    if ((c & (WGBC_TABW / BK - 1)) == 0 && c > 0) {   // every earlier chunk has read its table entries
+      __syncthreads();
+      build_window(c / (WGBC_TABW / BK));
+      __syncthreads();
+    }
     if (isA) {
       const int2* tp = tab + ((c * BK) & (WGBC_TABW - 1)) + 8 * rg;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int2 e = tp[k];
         const unsigned m = (unsigned)__builtin_amdgcn_sbfe(e.y, atap, 1);   // 0 or 0xFFFFFFFF
-        ra[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)(e.x + a_const) | m, 0, 0);
+        ra[k] = __builtin_amdgcn_raw_buffer_load_b128(rBig, (unsigned)(e.x + a_const) | m, 0, 0);
       }
     } else {
       const int soff = (r_begin + c * BK) * p.Cs * 2;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) ra[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, b_voff[k], soff, 0);
+      for (int k = 0; k < 8; ++k) ra[k] = __builtin_amdgcn_raw_buffer_load_b128(rSmall, b_voff[k], soff, 0);
     }
   };
 
   // ra[k][d] = channels (2d, 2d+1) of row k  ->  per channel the 8 rows as four dwords (k0k1, k2k3, k4k5, k6k7)
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](const Stage& sg, int buf) {
     if (!active) return;
+    const v4u (&ra)[8] = sg.ra;
     __bf16* d = lds_dst + buf * lds_elems;
 #pragma unroll
     for (int dp = 0; dp < 4; ++dp) {
@@ -328,19 +338,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16c_kernel(const WGParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  build_window(0);
-  __syncthreads();
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
-
-  for (int c = 0; c < nchunks; ++c) {
-    const int cur = c & 1;
-    if (((c + 1) & (WGBC_TABW / BK - 1)) == 0) {   // the loads of chunk c were issued an iteration ago
-      build_window((c + 1) / (WGBC_TABW / BK));
-      __syncthreads();
-    }
-    load_chunk(c + 1);  // past the end: out-of-range offsets -> zeros, never read
+  auto compute = [&](int cur) {
     const __bf16* as = As + cur * A_ELEMS + (wm * WTM + l31) * LDKH + 8 * lh;
     const __bf16* bs = Bs + cur * B_ELEMS + (wn * WTN + l31) * LDKH + 8 * lh;
 #pragma unroll
@@ -356,7 +354,26 @@ __global__ __launch_bounds__(256) void wgrad_bf16c_kernel(const WGParams p) {
         for (int j = 0; j < NT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
-    store_chunk(cur ^ 1);
+  };
+
+  // two chunks of global loads in flight (a chunk's MFMAs take ~0.2 us, a load far longer), one barrier per chunk;
+  // chunks past the end read zeros (every table row >= r_end is masked) and are never multiplied
+  build_window(0);
+  __syncthreads();
+  Stage s0, s1;
+  load_chunk(s0, 0);
+  store_chunk(s0, 0);
+  load_chunk(s0, 1);
+  __syncthreads();
+  for (int c = 0; c < nchunks; c += 2) {
+    load_chunk(s1, c + 2);
+    compute(0);
+    store_chunk(s0, 1);
+    __syncthreads();
+    if (c + 1 >= nchunks) break;   // uniform
+    load_chunk(s0, c + 3);
+    compute(1);
+    store_chunk(s1, 0);
     __syncthreads();
   }
 
