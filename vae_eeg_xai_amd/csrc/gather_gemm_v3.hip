@@ -57,7 +57,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   const int lh = lane >> 5, l31 = lane & 31;
 
   int bnt, btile, kz;
-  veex_block_coords(p.remap, p.gx, p.gy, bnt, btile, kz);
+  if (p.remap == 2) {
+    // row_order 1, one phase: the tiles (image row y, sample group g) of ALL y go to XCD g % 8 (workgroups are dealt
+    // round-robin over the XCDs), in y-major order: a sample group's input rows are shared by three consecutive
+    // output rows, and meet in ONE L2 (deconv4 forward: 291 -> 94 MB fetched, -11 % time vs the chunked order)
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int rest = local / p.gx, gq = p.row_tiles >> 3;
+    bnt = local - rest * p.gx;
+    const int y = rest / gq, g8 = rest - y * gq;
+    btile = y * p.row_tiles + g8 * 8 + xcd;
+    kz = 0;
+  } else {
+    veex_block_coords(p.remap, p.gx, p.gy, bnt, btile, kz);
+  }
   int tile = btile, ph = 0;
   if (p.nphase == 4) {
     while (ph < 3 && tile >= p.tile_prefix[ph + 1]) ++ph;
@@ -382,6 +394,15 @@ int veex_launch_gather_gemm_v3(GGParams& p, int mtiles, hipStream_t st) {
   // those launches, +3 % on a launch without padding, whose tiles then only lose locality)
   const bool vpad = (p.mode == 1) ? true : (p.pb > 0 || (p.Hout - 1) * p.stride + p.kh - 1 - p.pb >= p.Hin);
   p.row_order = (p.kh > 1 && p.nsplit == 1 && vpad) ? veex_env_int("VEEX_ROWORD", 1) : 0;
+  if (p.row_order == 1 && xr < 0) {
+    // the chunked XCD order would split a sample group's image rows over the XCDs: group-per-XCD order where the
+    // tiles line up with the image rows, plain round-robin otherwise
+    const long long rowlen = (long long)p.Nb * p.Wout;
+    p.remap = 0;
+    if (p.nphase == 1 && rowlen % 64 == 0 && (rowlen / 64) % 8 == 0 && (long long)mtiles == p.Hout * (rowlen / 64)) {
+      p.remap = 2; p.row_tiles = (int)(rowlen / 64);
+    }
+  }
   const int aff = (p.a_scale == nullptr) ? 0 : (p.aff_spatial ? 2 : 1);
   if (p.mode == 1) gg3_launch<true>(p, aff, grid, st);
   else gg3_launch<false>(p, aff, grid, st);

@@ -52,6 +52,7 @@ struct GGParams {
   int o_cmask;           // o_scale index = col & o_cmask
   int dbg;               // timing-only switches of the bf16 engine (VEEX_DBG; results are wrong when non-zero)
   int row_order;         // lean fp32 kernel: 0 = tile rows run over (n, y, x), 1 = over (y, n, x) -- one image row per tile
+  int row_tiles;         // remap == 2 (row_order 1): m tiles per image row (a multiple of 8); XCD x owns the tiles g % 8 == x of every row
 };
 
 // ---------------------------------------------------------------------------
