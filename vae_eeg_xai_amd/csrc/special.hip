@@ -120,35 +120,96 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 // dx[n][iy][ix] = sum_{ky,kx,co} dpre1[n][(iy-ky)/2][(ix-kx)/2][co] * W1[ky][kx][co]  (attribution only)
-// One block per sample, dpre1 streamed exactly once (coalesced float4 per lane, next pixel prefetched):
-//   phase 1: per conv1 output pixel the 9 tap dot products over 64 channels (16 lanes x 4 channels, the 9x4
-//            weights in registers, DPP row sums) -> T[400][9] in LDS
+// One block per sample, dpre1 streamed exactly once:
+//   phase 1: per conv1 output pixel the 9 tap dot products over 64 channels -> T[400][9] in LDS.  Tiles of 64
+//            pixels are staged through LDS with coalesced 16-byte loads (the next tile's loads are in flight while
+//            this one is multiplied); lane = pixel, wave = channel quarter, so the 9x16 weights of a wave are
+//            wave-uniform (scalar registers) and a pixel costs 144 v_fmac per lane with no cross-lane reduction
+//            (the 16-lane DPP version spent as much on the row sums as on the products: VALU-bound at 2x the
+//            memory time); the four quarter sums meet in LDS.
 //   phase 2: per input pixel gather its <= 4 contributions from T, times mul (gradient*input), store.
+#define C1D_TP 64            // pixels per tile
+#define C1D_LD 68            // padded tile row (floats): 17 sixteen-byte slots, conflict-free ds_read_b128 per lane
 __global__ __launch_bounds__(256) void conv1_dgrad_kernel(const float* __restrict__ dpre, const float* __restrict__ W,
                                                           const float* __restrict__ mul, float* __restrict__ dx) {
+  __shared__ __attribute__((aligned(16))) float sX[C1D_TP * C1D_LD];
+  __shared__ float sP[3][C1D_TP * 9];
   __shared__ float sT[C1H * C1H * 9];
   const int n = blockIdx.x, tid = threadIdx.x;
-  const int cq = tid & 15, pg = tid >> 4;
-  float4 w[9];
+  const int qtr = __builtin_amdgcn_readfirstlane(tid >> 6);   // channel quarter = wave
+  const int pl = tid & 63;
+  const float* wq = W + 16 * qtr;                              // W[t*64 + c]
+  const float4* src4 = reinterpret_cast<const float4*>(dpre + (long long)n * (C1H * C1H * NCH));
+  constexpr int NPIX = C1H * C1H, NT = (NPIX + C1D_TP - 1) / C1D_TP;
+  // staging: tile pixel i>>4, float4 column i&15 for i = tid + 256*k; two tiles of loads in flight per block
+  struct Stage { float4 v[4]; };
+  auto load_tile = [&](Stage& sg, int t) {
+    const int t0 = t * C1D_TP;
+    const int np = min(C1D_TP, NPIX - t0);   // <= 0 past the end: nothing is loaded
 #pragma unroll
-  for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const float4*>(W + t * NCH + 4 * cq);
-  const float* src = dpre + (long long)n * (C1H * C1H * NCH) + 4 * cq;
-  float4 nxt = *reinterpret_cast<const float4*>(src + pg * NCH);
-  for (int pix = pg; pix < C1H * C1H; pix += 16) {
-    const float4 v = nxt;
-    if (pix + 16 < C1H * C1H) nxt = *reinterpret_cast<const float4*>(src + (pix + 16) * NCH);
-    float keep = 0.f;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      float a = v.x * w[t].x;
-      a = fmaf(v.y, w[t].y, a); a = fmaf(v.z, w[t].z, a); a = fmaf(v.w, w[t].w, a);
-      a = row16_sum(a);
-      keep = (cq == t) ? a : keep;
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + 256 * k;
+      sg.v[k] = ((i >> 4) < np) ? src4[t0 * 16 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (cq < 9) sT[pix * 9 + cq] = keep;
+  };
+  Stage s0, s1;
+  load_tile(s0, 0);
+  load_tile(s1, 1);
+  // the multipliers of phase 2 (gradient * input) are fetched now: a load per output inside that loop costs its
+  // full latency seven times per block
+  float mreg[(IMG * IMG + 255) / 256];
+#pragma unroll
+  for (int k = 0; k < (IMG * IMG + 255) / 256; ++k) {
+    const int o = tid + 256 * k;
+    mreg[k] = (mul != nullptr && o < IMG * IMG) ? mul[(long long)n * (IMG * IMG) + o] : 1.f;
+  }
+  auto step = [&](Stage& sg, int t) {
+    const int t0 = t * C1D_TP;
+    const int np = min(C1D_TP, NPIX - t0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + 256 * k;
+      *reinterpret_cast<float4*>(sX + (i >> 4) * C1D_LD + 4 * (i & 15)) = sg.v[k];
+    }
+    __syncthreads();
+    load_tile(sg, t + 2);
+    float x[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float4 v = *reinterpret_cast<const float4*>(sX + pl * C1D_LD + 16 * qtr + 4 * c);
+      x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
+    }
+    float a[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) sacc = fmaf(x[c], wq[tp * NCH + c], sacc);
+      a[tp] = sacc;
+    }
+    if (qtr > 0) {
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) sP[qtr - 1][pl * 9 + tp] = a[tp];
+    }
+    __syncthreads();
+    if (qtr == 0 && pl < np) {
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp)
+        sT[(t0 + pl) * 9 + tp] = ((a[tp] + sP[0][pl * 9 + tp]) + sP[1][pl * 9 + tp]) + sP[2][pl * 9 + tp];
+    }
+    // (the next tile's sX / sP writes come after this tile's reads: sX is read before the barrier above and
+    //  rewritten after it; sP is read here and rewritten only after the next tile's first barrier)
+  };
+  for (int t = 0; t < NT; t += 2) {
+    step(s0, t);
+    if (t + 1 < NT) step(s1, t + 1);
   }
   __syncthreads();
-  for (int o = tid; o < IMG * IMG; o += 256) {
+  constexpr int NO = (IMG * IMG + 255) / 256;
+#pragma unroll
+  for (int k = 0; k < NO; ++k) {
+    const int o = tid + 256 * k;
+    if (o >= IMG * IMG) break;
     const int iy = o / IMG, ix = o - iy * IMG;
     float s = 0.f;
 #pragma unroll
@@ -162,8 +223,7 @@ __global__ __launch_bounds__(256) void conv1_dgrad_kernel(const float* __restric
         s += sT[((ty >> 1) * C1H + (tx >> 1)) * 9 + ky * 3 + kx];
       }
     }
-    const long long oi = (long long)n * (IMG * IMG) + o;
-    dx[oi] = (mul != nullptr) ? s * mul[oi] : s;
+    dx[(long long)n * (IMG * IMG) + o] = s * mreg[k];
   }
 }
 
