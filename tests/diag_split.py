@@ -5,7 +5,7 @@ from oracle import vae_oracle as vo
 from vae_eeg_xai_amd.net import Net
 L, B = 28, 512
 net = Net(L, "vae"); net.init_weights(seed=0)
-x = vo.synth_topomaps(B, 77)
+x = vo.synth_topomaps(B, 77)   # (checker: lives under tests/ because it uses the oracle)
 eps = np.random.default_rng(1).standard_normal((B, L)).astype(np.float32)
 names = ["act.enc.conv1","act.enc.conv2","act.enc.conv3","act.enc.dense","mulv","z","act.dec.dense","act.dec.deconv1","act.dec.deconv5","dlogit",
          "dpre.dec.deconv5","dpre.dec.deconv1","g.dec.dense","dpre.dec.dense","dz","dmulv","dpre.enc.dense","dpre.enc.conv3","dpre.enc.conv1"]

@@ -4,11 +4,11 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vae_eeg_xai_amd.net import Net
-from oracle import vae_oracle as vo
+from bench import synth
 var, vals = sys.argv[1], sys.argv[2:]
 B = 4096
 net = Net(28, "vae"); net.init_weights(seed=1)
-x = torch.from_numpy(vo.synth_topomaps(B, 3)).cuda()
+x = torch.from_numpy(synth(B, seed=3)).cuda()
 units = list(range(28))
 for rnd in range(3):
     for v in vals:

@@ -3,11 +3,11 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vae_eeg_xai_amd.net import Net
-from oracle import vae_oracle as vo
+from bench import synth
 
 for B in (32, 64, 128, 512):
     net = Net(28, "vae"); net.init_weights(seed=1)
-    x = torch.from_numpy(vo.synth_topomaps(B, 3)).cuda()
+    x = torch.from_numpy(synth(B, seed=3)).cuda()
     eps = torch.randn(B, 28, device="cuda")
     def step():
         net.train_fwd_bwd(x, eps, accumulate_metrics=True)
