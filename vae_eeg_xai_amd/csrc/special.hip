@@ -77,20 +77,36 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
   float4 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int pix = blockIdx.x * 16 + pg; pix < npix; pix += gridDim.x * 16) {
-    const int n = pix / (C1H * C1H), rem = pix - n * (C1H * C1H);
-    const int oy = rem / C1H, ox = rem - oy * C1H;
-    const float* xs = x + (long long)n * (IMG * IMG);
-    const float4 g = *reinterpret_cast<const float4*>(dpre + (long long)pix * NCH + 4 * cq);
+  // two pixels per trip (25 dependent trips per thread otherwise): both gradients and 2 x 9 inputs in flight
+  const int pstride = gridDim.x * 16;
+  for (int pix0 = blockIdx.x * 16 + pg; pix0 < npix; pix0 += 2 * pstride) {
+    float v[2][9];
+    float4 g[2];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = 2 * oy + ky;
+    for (int u = 0; u < 2; ++u) {
+      const int pix = pix0 + u * pstride;
+      const bool live = pix < npix;
+      const int n = pix / (C1H * C1H), rem = pix - n * (C1H * C1H);
+      const int oy = rem / C1H, ox = rem - oy * C1H;
+      const float* xs = x + (long long)n * (IMG * IMG);
+      g[u] = live ? *reinterpret_cast<const float4*>(dpre + (long long)pix * NCH + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = 2 * ox + kx;
-        const float v = (iy < IMG && ix < IMG) ? xs[iy * IMG + ix] : 0.f;
-        float4& a = acc[ky * 3 + kx];
-        a.x = fmaf(v, g.x, a.x); a.y = fmaf(v, g.y, a.y); a.z = fmaf(v, g.z, a.z); a.w = fmaf(v, g.w, a.w);
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * oy + ky;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = 2 * ox + kx;
+          v[u][ky * 3 + kx] = (live && iy < IMG && ix < IMG) ? xs[iy * IMG + ix] : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        float4& a = acc[t];
+        a.x = fmaf(v[u][t], g[u].x, a.x); a.y = fmaf(v[u][t], g[u].y, a.y);
+        a.z = fmaf(v[u][t], g[u].z, a.z); a.w = fmaf(v[u][t], g[u].w, a.w);
       }
     }
   }
@@ -254,27 +270,44 @@ __global__ __launch_bounds__(D6_THREADS) void deconv6_bce_fwd_kernel(
   }
   const float* src = a5 + (long long)n * (D5H * D5H * NCH);
   constexpr int NIT = (D5H * D5H + NPG - 1) / NPG;
-  for (int it = 0; it < NIT; ++it) {
-    const int pix = it * NPG + pg;
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
-    if (pix < D5H * D5H) {
-      float4 a = *reinterpret_cast<const float4*>(src + pix * NCH + 4 * cq);
+  // the targets of phase 2 are fetched now (a load per output inside that loop pays its full latency each time)
+  constexpr int NO = (IMG * IMG + D6_THREADS - 1) / D6_THREADS;
+  float treg[NO];
+#pragma unroll
+  for (int k = 0; k < NO; ++k) {
+    const int o = threadIdx.x + D6_THREADS * k;
+    treg[k] = (target != nullptr && o < IMG * IMG) ? target[(long long)n * (IMG * IMG) + o] : 0.f;
+  }
+  constexpr int PF = 4;   // pixels in flight per lane
+  for (int it0 = 0; it0 < NIT; it0 += PF) {
+    float4 av[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int pix = (it0 + u) * NPG + pg;
+      av[u] = (pix < D5H * D5H) ? *reinterpret_cast<const float4*>(src + pix * NCH + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int pix = (it0 + u) * NPG + pg;
+      float4 a = av[u];
       a.x = fmaf(a.x, sc.x, sh.x); a.y = fmaf(a.y, sc.y, sh.y); a.z = fmaf(a.z, sc.z, sh.z); a.w = fmaf(a.w, sc.w, sh.w);
+      float s[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         float v = a.x * w[t].x;
         v = fmaf(a.y, w[t].y, v); v = fmaf(a.z, w[t].z, v); v = fmaf(a.w, w[t].w, v);
-        s[t] = v;
+        s[t] = row16_sum(v);
       }
+      if (cq == 0 && pix < D5H * D5H) *reinterpret_cast<float4*>(d + pix * 4) = make_float4(s[0], s[1], s[2], s[3]);
     }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) s[t] = row16_sum(s[t]);
-    if (cq == 0 && pix < D5H * D5H) *reinterpret_cast<float4*>(d + pix * 4) = make_float4(s[0], s[1], s[2], s[3]);
   }
   __syncthreads();
   const float bias = b6[0];
   float bce_sum = 0.f, dl_sum = 0.f;
-  for (int o = threadIdx.x; o < IMG * IMG; o += D6_THREADS) {
+#pragma unroll
+  for (int k = 0; k < NO; ++k) {
+    const int o = threadIdx.x + D6_THREADS * k;
+    if (o >= IMG * IMG) break;
     const int oy = o / IMG, ox = o - oy * IMG;
     float a = bias;
 #pragma unroll
@@ -294,7 +327,7 @@ __global__ __launch_bounds__(D6_THREADS) void deconv6_bce_fwd_kernel(
     if (logits != nullptr) logits[oi] = a;
     if (recon != nullptr) recon[oi] = sg;
     if (target != nullptr) {
-      const float t = target[oi];
+      const float t = treg[k];
       bce_sum += fmaxf(a, 0.f) - a * t + log1pf(e);
       const float dl = (sg - t) * inv_batch;
       dl_sum += dl;
@@ -342,9 +375,20 @@ __global__ __launch_bounds__(D6_THREADS) void deconv6_bwd_kernel(
   __syncthreads();
   const float* src = a5 + (long long)n * (D5H * D5H * NCH);
   float* dst = dpre5 + (long long)n * (D5H * D5H * NCH);
-  for (int pix = pg; pix < D5H * D5H; pix += NPG) {
+  constexpr int PF = 4;   // pixels in flight per lane (48 trips of one dependent 16-byte load each otherwise)
+  for (int pix0 = pg; pix0 < D5H * D5H; pix0 += PF * NPG) {
+    float4 av[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int pix = pix0 + u * NPG;
+      av[u] = (pix < D5H * D5H) ? *reinterpret_cast<const float4*>(src + pix * NCH + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+    const int pix = pix0 + u * NPG;
+    if (pix >= D5H * D5H) break;
     const int iy = pix / D5H, ix = pix - iy * D5H;
-    const float4 a = *reinterpret_cast<const float4*>(src + pix * NCH + 4 * cq);
+    const float4 a = av[u];
     float4 y;
     y.x = fmaf(a.x, sc.x, sh.x); y.y = fmaf(a.y, sc.y, sh.y); y.z = fmaf(a.z, sc.z, sh.z); y.w = fmaf(a.w, sc.w, sh.w);
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -368,6 +412,7 @@ __global__ __launch_bounds__(D6_THREADS) void deconv6_bwd_kernel(
       bf16x4_t h;
       h[0] = (__bf16)o.x; h[1] = (__bf16)o.y; h[2] = (__bf16)o.z; h[3] = (__bf16)o.w;
       *reinterpret_cast<bf16x4_t*>(dpre5_bf + (long long)n * (D5H * D5H * NCH) + pix * NCH + 4 * cq) = h;
+    }
     }
   }
 #pragma unroll
