@@ -517,11 +517,20 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_rows_kernel(const float* __res
   const int r0 = blockIdx.y * BRB_ROWS, r1 = min(R, r0 + BRB_ROWS);
   const float sc = (e_scale != nullptr) ? e_scale[c & cmask] : 1.f;
   float s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  for (int r = r0; r < r1; ++r) {
-    const long long i = (long long)r * C + c;
-    const float v = g[i];
-    float a = 1.f;
-    if (aux != nullptr) { a = aux[i]; s2 = fmaf(v, a, s2); }
+  float gv[BRB_ROWS], av[BRB_ROWS];   // all loads of the chunk first: the rows are independent
+#pragma unroll
+  for (int k = 0; k < BRB_ROWS; ++k) {
+    const long long i = (long long)(r0 + k) * C + c;
+    const bool live = r0 + k < r1;
+    gv[k] = live ? g[i] : 0.f;
+    av[k] = (live && aux != nullptr) ? aux[i] : 1.f;
+  }
+#pragma unroll
+  for (int k = 0; k < BRB_ROWS; ++k) {
+    if (r0 + k >= r1) break;
+    const long long i = (long long)(r0 + k) * C + c;
+    const float v = gv[k], a = av[k];
+    if (aux != nullptr) s2 = fmaf(v, a, s2);
     const bool on = a > 0.f;
     s1 += v;
     s3 += on ? v : 0.f;
@@ -636,7 +645,13 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
                                                        const float* __restrict__ bias, int ncols, int relu) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += slab[(long long)k * stride + i];
+    int k = 0;
+    for (; k + 3 < nsplit; k += 4) {   // four independent loads in flight, added in slab order
+      const float v0 = slab[(long long)k * stride + i], v1 = slab[(long long)(k + 1) * stride + i];
+      const float v2 = slab[(long long)(k + 2) * stride + i], v3 = slab[(long long)(k + 3) * stride + i];
+      s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; k < nsplit; ++k) s += slab[(long long)k * stride + i];
     if (bias != nullptr) s += bias[(int)(i % ncols)];
     if (relu) s = fmaxf(s, 0.f);
     out[i] = s;
@@ -678,8 +693,15 @@ __global__ __launch_bounds__(64 * LY) void slab_sum_tall_kernel(const float* __r
   const int cx = threadIdx.x & 63, ly = threadIdx.x >> 6;
   const long long i = (long long)blockIdx.x * 64 + cx;
   float s = 0.f;
-  if (i < n)
-    for (int k = ly; k < nsplit; k += LY) s += slab[(long long)k * stride + i];
+  if (i < n) {   // four independent loads in flight, added in slab order
+    int k = ly;
+    for (; k + 3 * LY < nsplit; k += 4 * LY) {
+      const float v0 = slab[(long long)k * stride + i], v1 = slab[(long long)(k + LY) * stride + i];
+      const float v2 = slab[(long long)(k + 2 * LY) * stride + i], v3 = slab[(long long)(k + 3 * LY) * stride + i];
+      s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; k < nsplit; k += LY) s += slab[(long long)k * stride + i];
+  }
   red[ly][cx] = s;
   __syncthreads();
   if (ly == 0 && i < n) {
