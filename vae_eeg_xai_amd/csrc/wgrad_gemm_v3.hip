@@ -55,23 +55,27 @@ __global__ __launch_bounds__(256) void wgrad_v3_kernel(const WGParams p) {
 
   // ---- row table ----
   {
+    // (float reciprocals + one correction step instead of two 32-bit integer divisions, and the tap mask composed
+    //  from a column mask and the valid kernel rows: ~50 instead of ~200 instructions per row -- with up to 12
+    //  rows per thread the table cost 8 % of a block's MFMA time)
     const int HWs = p.Hs * p.Ws;
-    const int ntaps = p.kh * p.kw;
+    const float invHWs = 1.0f / (float)HWs, invWs = 1.0f / (float)p.Ws;   // rows < 2^24 (veex_wgrad_v3_ok)
     for (int t = tid; t < nchunks * BK; t += 256) {
       const int r = r_begin + t;
       int off = 0;
       unsigned inv = 0xFFFFFFFFu;
       if (r < r_end) {
-        const int n = r / HWs, rem = r - n * HWs;
-        const int py = rem / p.Ws, px = rem - py * p.Ws;
+        int n = (int)((float)r * invHWs), rem = r - n * HWs;
+        if (rem < 0) { n -= 1; rem += HWs; }
+        if (rem >= HWs) { n += 1; rem -= HWs; }
+        int py = (int)((float)rem * invWs), px = rem - py * p.Ws;
+        if (px < 0) { py -= 1; px += p.Ws; }
+        if (px >= p.Ws) { py += 1; px -= p.Ws; }
         const int y0 = p.stride * py - p.pb, x0 = p.stride * px - p.pb;
         off = (((n * p.Hb + y0) * p.Wb + x0) * p.Cb) * 4;   // may be "virtual" (negative) at the border
-        unsigned mk = 0u;
-        for (int tp = 0; tp < ntaps; ++tp) {
-          const int ky = tp / p.kw, kx = tp - ky * p.kw;
-          const int by = y0 + ky, bx = x0 + kx;
-          if (by >= 0 && by < p.Hb && bx >= 0 && bx < p.Wb) mk |= 1u << tp;
-        }
+        unsigned xb = 0u, mk = 0u;
+        for (int kx = 0; kx < p.kw; ++kx) if (x0 + kx >= 0 && x0 + kx < p.Wb) xb |= 1u << kx;
+        for (int ky = 0; ky < p.kh; ++ky) if (y0 + ky >= 0 && y0 + ky < p.Hb) mk |= xb << (ky * p.kw);
         inv = ~mk;
       }
       tab[t] = make_int2(off, (int)inv);
@@ -248,6 +252,7 @@ int veex_wgrad_v3_ok(const WGParams& p) {
   if (p.b_scale != nullptr && (p.s_scale != nullptr || p.b_aff_spatial)) return 0;
   if (p.s_scale != nullptr && p.s_aff_spatial && (p.s_aff_mask + 1) != p.Hs * p.Ws * p.Cs) return 0;
   if (p.rows_per_split > VEEX_WG3_MAX_ROWS) return 0;
+  if (p.R >= (1 << 24)) return 0;   // the row table divides with float reciprocals
   return 1;
 }
 
