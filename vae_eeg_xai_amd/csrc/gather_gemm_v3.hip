@@ -102,16 +102,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   };
 
   if (tid == 0) *s_tmk = 0u;
-  if (tid < BM) {
-    const int m = m0 + tid;
-    unsigned off = 0x80000000u;   // + any column offset stays out of range: the store is dropped
-    if (m < Mph) {
-      int n, j, i;
-      row_nji(m, n, j, i);
-      off = (unsigned)(((n * p.Hout + ostep * j + oy0) * p.Wout + ostep * i + ox0) * p.Cout) * 4u;
-    }
-    s_offb[tid] = off;
-  }
 
   // Bias: the scalar offset of a tap must be >= 0, so the per-row offset is taken at the tap with the lowest
   // address; for rows at the top-left border that pixel lies before the tensor, hence every per-row offset
@@ -136,10 +126,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   unsigned a_voff = 0u, a_voff2 = 0u, a_inv = 0xFFFFFFFFu;   // a_inv bit t set <=> tap t must read zeros
   {
     const int m = m0 + lr;
+    unsigned out_off = 0x80000000u;   // + any column offset stays out of range: the store is dropped
     if (m < Mph) {
       int n, j, ii;
       row_nji(m, n, j, ii);
       const int oy = ostep * j + oy0, ox = ostep * ii + ox0;
+      out_off = (unsigned)(((n * p.Hout + oy) * p.Wout + ox) * p.Cout) * 4u;
       int by, bx;   // input pixel read by phase tap (0,0)
       if (MODE1) { by = (oy + p.pb - kys) >> (p.stride - 1); bx = (ox + p.pb - kxs) >> (p.stride - 1); }
       else       { by = p.stride * oy - p.pb; bx = p.stride * ox - p.pb; }
@@ -148,16 +140,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
       const int inner = ((MODE1 ? (by * p.Win + bx) : ((by + p.pb) * p.Win + bx + p.pb)) * p.Cin + 4 * q) * 4;
       a_voff = (unsigned)(nbase + inner);
       a_voff2 = (unsigned)inner;
-      unsigned mk = 0u;
-      for (int ia = 0; ia < nky; ++ia)
-        for (int ib = 0; ib < nkx; ++ib) {
-          const int iy = MODE1 ? by - ia : by + ia, ix = MODE1 ? bx - ib : bx + ib;
-          bool ok = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-          if (MODE1) ok = ok && (oy + p.pb - (kys + kstep * ia)) >= 0 && (ox + p.pb - (kxs + kstep * ib)) >= 0;
-          if (ok) mk |= 1u << (ia * nkx + ib);
-        }
+      // tap (ia, ib) is valid iff its row is and its column is: a column mask, shifted in for every valid row
+      unsigned xb = 0u, mk = 0u;
+      for (int ib = 0; ib < nkx; ++ib) {
+        const int ix = MODE1 ? bx - ib : bx + ib;
+        bool ok = ix >= 0 && ix < p.Win;
+        if (MODE1) ok = ok && (ox + p.pb - (kxs + kstep * ib)) >= 0;
+        if (ok) xb |= 1u << ib;
+      }
+      for (int ia = 0; ia < nky; ++ia) {
+        const int iy = MODE1 ? by - ia : by + ia;
+        bool ok = iy >= 0 && iy < p.Hin;
+        if (MODE1) ok = ok && (oy + p.pb - (kys + kstep * ia)) >= 0;
+        if (ok) mk |= xb << (ia * nkx);
+      }
       a_inv = ~mk;   // bits >= ntaps (bit 31 included: "chunk past the end") stay set
     }
+    if (q == 0) s_offb[lr] = out_off;   // the epilogue's output row byte offsets (read after the K loop's barriers)
   }
   // valid-tap set of the tile: split-K launches keep every tap (their chunk ranges are planned on the host)
   __syncthreads();
