@@ -296,23 +296,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     } else if (p.epi == VEEX_EPI_BWD) {
       const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.aux), 0, (int)out_bytes, 0x00020000);
       const float esc = (p.e_scale != nullptr) ? p.e_scale[col & p.epi_cmask] : 1.f;
+      // all 16 activations first: loads and stores go through different descriptors the compiler cannot tell apart,
+      // so four load-use-store groups would pay four memory latencies per tile
+      unsigned rof[16];
+      float a[16];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const uint4 ro = *reinterpret_cast<const uint4*>(s_offb + wm * 32 + 8 * g + 4 * lh);
-        const unsigned rof[4] = {ro.x, ro.y, ro.z, ro.w};
-        float a[4];
+        rof[4 * g] = ro.x; rof[4 * g + 1] = ro.y; rof[4 * g + 2] = ro.z; rof[4 * g + 3] = ro.w;
+      }
 #pragma unroll
-        for (int e = 0; e < 4; ++e)   // rows past M: out of range -> 0 (and their accumulators are 0)
-          a[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rX, rof[e] + col4, 0, 0));
+      for (int r = 0; r < 16; ++r)   // rows past M: out of range -> 0 (and their accumulators are 0)
+        a[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rX, rof[r] + col4, 0, 0));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = acc[4 * g + e];
-          const float vm = (!p.relu || a[e] > 0.f) ? v : 0.f;
-          cs1 += v;
-          cs2 = fmaf(v, a[e], cs2);
-          cs3 += vm;
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vm * esc), rO, rof[e] + col4, 0, 0);
-        }
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[r];
+        const float vm = (!p.relu || a[r] > 0.f) ? v : 0.f;
+        cs1 += v;
+        cs2 = fmaf(v, a[r], cs2);
+        cs3 += vm;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vm * esc), rO, rof[r] + col4, 0, 0);
       }
     } else {
 #pragma unroll
