@@ -70,6 +70,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   } else {
     veex_block_coords(p.remap, p.gx, p.gy, bnt, btile, kz);
   }
+  // (say so: once the compiler lost track of their uniformity, every scalar offset derived from them moved into
+  //  VGPRs and each buffer load of the K loop became a readfirstlane "waterfall" loop)
+  bnt = __builtin_amdgcn_readfirstlane(bnt);
+  btile = __builtin_amdgcn_readfirstlane(btile);
+  kz = __builtin_amdgcn_readfirstlane(kz);
   int tile = btile, ph = 0;
   if (p.nphase == 4) {
     while (ph < 3 && tile >= p.tile_prefix[ph + 1]) ++ph;
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   int it_cc = (nvalid > 0) ? c_begin / nvalid : 0;
   unsigned it_bits = tile_mk;
   for (int k = c_begin - it_cc * nvalid; k > 0; --k) it_bits &= it_bits - 1u;   // (split-K: tile_mk is the full set)
-  const int inv_nkx = 65536 / nkx + 1;   // tapi / nkx for tapi < 32
+  const int inv_nkx = __builtin_amdgcn_readfirstlane(65536 / nkx + 1);   // tapi / nkx for tapi < 32
 
   auto load_chunk = [&](Stage& st) {
     const bool cvalid = it_c < c_end;
