@@ -63,6 +63,9 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GGParams p)
 
   int bnt, btile, kz;
   veex_block_coords(p.remap, p.gx, p.gy, bnt, btile, kz);
+  bnt = __builtin_amdgcn_readfirstlane(bnt);     // wave-uniform: everything derived from them stays in SGPRs
+  btile = __builtin_amdgcn_readfirstlane(btile);
+  kz = __builtin_amdgcn_readfirstlane(kz);
   int tile = btile, ph = 0;
   if (p.nphase == 4) {
     while (ph < 3 && tile >= p.tile_prefix[ph + 1]) ++ph;
@@ -158,10 +161,21 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GGParams p)
     bool rok[APASS];
   };
 
-  auto load_chunk = [&](Stage& st, int c, bool cvalid) {
-    const int cc = p.tap_inner ? c / ntaps : c % cpt;
-    const int tapi = p.tap_inner ? c - cc * ntaps : c / cpt;
-    const int ia = tapi / nkx, ib = tapi - ia * nkx;
+  // running (channel slice, tap) of the next chunk to load: chunks are loaded strictly in order, channel slice outer /
+  // tap inner.  (Recomputing them per chunk cost three scalar integer divisions = ~55 SALU instructions and, with the
+  // timing switches that used to sit in this loop, ~10 branches per 4-8 MFMAs: the loop was bound by instruction
+  // issue, not by the MFMAs or the loads.)
+  int it_cc = c_begin / ntaps;
+  int it_tapi = c_begin - it_cc * ntaps;
+  int it_ia = it_tapi / nkx, it_ib = it_tapi - it_ia * nkx;
+  it_cc = __builtin_amdgcn_readfirstlane(it_cc); it_tapi = __builtin_amdgcn_readfirstlane(it_tapi);
+  it_ia = __builtin_amdgcn_readfirstlane(it_ia); it_ib = __builtin_amdgcn_readfirstlane(it_ib);
+
+  auto load_chunk = [&](Stage& st, bool cvalid) {
+    const int cc = it_cc, tapi = it_tapi, ia = it_ia, ib = it_ib;
+    ++it_tapi; ++it_ib;
+    if (it_ib == nkx) { it_ib = 0; ++it_ia; }
+    if (it_tapi == ntaps) { it_tapi = 0; it_ia = 0; it_ib = 0; ++it_cc; }
     const int tap = (kys + kstep * ia) * p.kw + (kxs + kstep * ib);
     const int ci0 = cc * BK;
     const int dpix = ia * p.Win + ib;
@@ -169,8 +183,7 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GGParams p)
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
       const bool ok = cvalid && ((a_mask[i] >> tapi) & 1u);
-      unsigned aoff = ok ? (unsigned)(a_rowbase[i] + delta) : VEEX_OOB;
-      if (p.dbg & 64) aoff = ok ? (aoff & 0xFF0u) : VEEX_OOB;   // timing-only: every A load hits the same 4 KiB
+      const unsigned aoff = ok ? (unsigned)(a_rowbase[i] + delta) : VEEX_OOB;
       st.ra[i] = bload4(rA, aoff);
       st.rok[i] = ok;
       if (AFF == 2) {
@@ -244,31 +257,19 @@ __global__ __launch_bounds__(256) void gather_gemm_bf16_kernel(const GGParams p)
 
   // two chunks of global loads in flight (see gather_gemm_kernel); one barrier per chunk
   Stage s0, s1;
-  load_chunk(s0, c_begin, c_begin < c_end);
+  load_chunk(s0, c_begin < c_end);
   store_chunk(s0, 0);
-  load_chunk(s0, c_begin + 1, c_begin + 1 < c_end);
+  load_chunk(s0, c_begin + 1 < c_end);
   __syncthreads();
-  const int dbg = p.dbg;   // timing-only: 1 no global loads in the loop, 2 no MFMA, 4 no barrier, 8 no LDS store, 16 no epilogue
   for (int c = c_begin; c < c_end; c += 2) {
-    if (!(dbg & 1)) load_chunk(s1, c + 2, c + 2 < c_end);
-    if (!(dbg & 2)) compute(0);
-    if (!(dbg & 8)) store_chunk(s0, 1);
-    if (!(dbg & 4)) __syncthreads();
-    if (!(dbg & 1)) load_chunk(s0, c + 3, c + 3 < c_end);
-    if (!(dbg & 2)) compute(1);
-    if (!(dbg & 8)) store_chunk(s1, 0);
-    if (!(dbg & 4)) __syncthreads();
-  }
-  if (dbg & 16) {
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) t += acc[i][j][r];
-    if (t == 1.2345f) p.Out[tid] = t;   // keeps the accumulators alive
-    return;
+    load_chunk(s1, c + 2 < c_end);
+    compute(0);
+    store_chunk(s0, 1);
+    __syncthreads();
+    load_chunk(s0, c + 3 < c_end);
+    compute(1);
+    store_chunk(s1, 0);
+    __syncthreads();
   }
   gg_epilogue_b<BM, BN, WM, WN>(p, acc, reinterpret_cast<const unsigned*>(s_off), reinterpret_cast<float*>(As), btile, kz, n0);
 }
@@ -388,8 +389,6 @@ int veex_launch_gather_gemm_bf16(GGParams& p, int mtiles, hipStream_t st) {
   }
   const int xr = veex_env_int("VEEX_XCD", -1);
   p.remap = (xr < 0) ? (p.nphase == 1) : xr;
-  p.tap_inner = veex_env_int("VEEX_TAPIN", 1);
-  p.dbg = veex_env_int("VEEX_DBG", 0);
   p.gx = ntiles; p.gy = mtiles; p.gz = p.nsplit;
   dim3 grid((unsigned)ntiles * mtiles * p.nsplit, 1, 1);
   if (bm == 64) return (p.mode == 1) ? ggb_launch<64, 64, true>(p, grid, st) : ggb_launch<64, 64, false>(p, grid, st);
