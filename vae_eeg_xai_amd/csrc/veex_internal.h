@@ -41,7 +41,7 @@ struct GGParams {
   long long slab_stride; // elements per split slab (RAW)
   int gx, gy, gz;        // logical grid (n tiles, m tiles, k splits), filled by the launcher
   int remap;             // 1: XCD-aware block order (veex_block_coords)
-  int tap_inner;         // K-chunk order: 1 = channel chunk outer / tap inner, 0 = tap outer
+  int tap_inner;         // general fp32 kernel: K-chunk order, 1 = channel chunk outer / tap inner, 0 = tap outer (the lean and bf16 kernels are always tap-inner)
   // bf16 "consumer copies" (bf16 compute only): the epilogue can also write what the NEXT bf16 GEMM
   // reads -- bf16(o_scale[c]*out + o_shift[c]) for a forward launch (this layer's BatchNorm applied),
   // bf16(out) for a gradient -- and the loader can read such a copy (no affine, no conversion).
@@ -50,7 +50,6 @@ struct GGParams {
   const float* o_scale;  // EPI_FWD: BatchNorm of THIS layer for OutBf (nullable: plain rounding)
   const float* o_shift;
   int o_cmask;           // o_scale index = col & o_cmask
-  int dbg;               // timing-only switches of the bf16 engine (VEEX_DBG; results are wrong when non-zero)
   int row_order;         // lean fp32 kernel: 0 = tile rows run over (n, y, x), 1 = over (y, n, x) -- one image row per tile
   int row_tiles;         // remap == 2 (row_order 1): m tiles per image row (a multiple of 8); XCD x owns the tiles g % 8 == x of every row
 };
