@@ -23,14 +23,23 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-LATENT = 28
-LOCAL_BATCH = 512
+LATENT = 28                # train.py:276; --latent sweeps it (configs[2]: 2, 8, 16, 28, 64, 128)
+LOCAL_BATCH = 512          # configs[1]: batch 512 on one GPU
+DP_LOCAL_BATCH = 1024      # configs[2]: global batch 8192 on 8 GPUs = 1024 per GPU
 N_TRAIN = 100_000          # config[1]: 100k synthetic topomaps
 LR = 1e-5
 
-# algorithmic work (SURVEY 8d / BASELINE.md section 2)
-FWD_MACS = 82_526_496
-TRAIN_MACS = 247_356_704
+
+# algorithmic work (SURVEY 8d / BASELINE.md section 2): exact in-bounds MACs per sample; the latent size enters
+# through the two heads (200 L) and the decoder's dense layer (4096 L)
+def fwd_macs(latent):
+    return 82_526_496 + (latent - 28) * (200 + 4096)
+
+
+def train_macs(latent):
+    return 3 * fwd_macs(latent) - 222_784      # fwd + every input gradient except conv1's + every weight gradient
+
+
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
@@ -54,37 +63,53 @@ def synth(n, seed=1234):
     return out
 
 
-def cpu_baseline(seconds_budget=15.0):
-    """config[0] on the host cores: the torch-CPU restatement (oracle/torch_ref.py, fp32, oneDNN)
-    of the reference train step, batch 64 -- kind 'port' (TensorFlow is not installable here)."""
+def host_threads():
+    """Threads this process may really use: its CPU affinity, capped by OMP_NUM_THREADS when the box sets it
+    (os.cpu_count() shows the whole machine, of which a one-GPU box owns a share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cap = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    return max(1, min(n, cap) if cap > 0 else n)
+
+
+def cpu_baseline():
+    """configs[0] exactly -- 1 000 synthetic maps, batch 64 (15 x 64 + 1 x 40 steps), one
+    epoch, L=28, Adam lr 1e-5 -- on the host cores with the torch-CPU fp32 restatement of the reference train step
+    (oracle/torch_ref.py, oneDNN; kind 'port': TensorFlow is not installable here).  One warm-up epoch, then the
+    median of 5 timed epochs."""
     import torch
     from oracle import torch_ref, vae_oracle as vo
-    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    cores = host_threads()
     torch.set_num_threads(cores)
-    p = vo.init_params(LATENT, "vae", seed=42)
-    x = synth(1000, seed=99)
+    p = vo.init_params(28, "vae", seed=42)
+    x = synth(1000, seed=1234)
     tr = torch_ref.TorchTrainer(p, LR, "vae", torch.float32)
-    tr.train_step(x[:64])            # warm-up
-    n_done, t0 = 0, time.perf_counter()
-    i = 0
-    while True:
-        xb = x[(i * 64) % 960:(i * 64) % 960 + 64]
-        tr.train_step(xb)
-        n_done += xb.shape[0]
-        i += 1
-        if time.perf_counter() - t0 > seconds_budget or i >= 2000:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": n_done / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{i} train steps of batch 64 (config[0] shape, 1k synthetic maps) in {dt:.1f}s, torch-CPU fp32 restatement"}
+
+    def epoch():
+        t0 = time.perf_counter()
+        for s in range(0, 1000, 64):
+            tr.train_step(x[s:s + 64])
+        return time.perf_counter() - t0
+
+    epoch()                          # warm-up
+    times = sorted(epoch() for _ in range(5))
+    med = times[2]
+    return {"value": 1000.0 / med, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"configs[0]: 1 epoch over 1000 synthetic maps, batch 64 (15x64 + 1x40 steps), L=28, Adam lr 1e-5; "
+                      f"median of 5 epochs after 1 warm-up ({med:.2f} s, min {times[0]:.2f}, max {times[-1]:.2f}); "
+                      f"torch-CPU fp32 restatement on {cores} threads (os.cpu_count() = {os.cpu_count()})"}
 
 
 ATTR_BATCH = 4096          # config[3]: attribution batches of 4096 maps
-ATTR_MACS_FWD = 14_177_584   # encoder forward without the unused log-variance head (SURVEY 8d)
-ATTR_MACS_BWD = 14_177_584   # encoder input-gradient chain incl. conv1
 
 
-def attribution_bench(net, x_all, world, iters=8, warmup=2):
+def attr_macs(latent):
+    """Encoder forward without the unused log-variance head = encoder input-gradient chain incl. conv1
+    (14 177 584 MACs at L=28; the z_mean head is 100 L of them)."""
+    return 14_174_784 + 100 * latent
+
+
+
+def attribution_bench(net, x_all, world, latent, iters=8, warmup=2):
     """config[3]: saliency maps d z_mean[:, j] / d x back to the 40x40 electrode grid, inputs sharded
     over ranks (replicas only, no collective).  One map = one (sample, latent unit) pair.  Returns
     whole-job maps/s for k=1 (analysis.py:725 picks the top-1 unit) and for all 28 units."""
@@ -93,7 +118,7 @@ def attribution_bench(net, x_all, world, iters=8, warmup=2):
     B = min(ATTR_BATCH, x_all.shape[0])
     nb = x_all.shape[0] // B
     out = {}
-    for label, units in (("top1", [3]), ("all28", list(range(LATENT)))):
+    for label, units in (("top1", [min(3, latent - 1)]), ("all", list(range(latent)))):
         def step(i):
             net.attribute(x_all[(i % nb) * B:(i % nb + 1) * B], units, grad_x_input=True)
         for i in range(warmup):
@@ -115,11 +140,11 @@ def attribution_bench(net, x_all, world, iters=8, warmup=2):
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dt = float(vdist.allreduce_max_(t).item())
         maps = iters * B * len(units) * world
-        flop = 2.0 * (ATTR_MACS_FWD * iters * B + ATTR_MACS_BWD * iters * B * len(units)) * world
+        flop = 2.0 * attr_macs(latent) * (iters * B + iters * B * len(units)) * world
         out[label] = {"maps_per_s": maps / dt, "ms_per_batch": 1e3 * dt / iters, "tflops": flop / dt / 1e12}
     return {"metric": "attribution maps/sec (gradient x input, latent unit -> 40x40 grid)", "unit": "maps/s",
-            "value": out["top1"]["maps_per_s"], "batch_per_gpu": B, "units": 1, "top1": out["top1"], "all28": out["all28"],
-            "sharding": "inputs split across ranks, replicas only"}
+            "value": out["top1"]["maps_per_s"], "batch_per_gpu": B, "units": 1, "top1": out["top1"],
+            f"all{latent}": out["all"], "sharding": "inputs split across ranks, replicas only"}
 
 
 def main():
@@ -127,7 +152,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=LOCAL_BATCH, help="local batch per GPU")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="local batch per GPU (default: 512 on one GPU = configs[1]; 1024 with --gpus > 1 = configs[2], "
+                         "global batch 8192 on 8 GPUs)")
+    ap.add_argument("--latent", type=int, default=LATENT, help="latent dimension (configs[2] sweeps 2, 8, 16, 28, 64, 128)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="arithmetic of the conv/deconv contractions: exact fp32 MFMA (parity path, default) or bf16 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -166,9 +194,11 @@ def main():
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
-    B = args.batch
-    note(f"world {world}, backend {backend if world > 1 else '-'}, batch {B}/GPU, {args.dtype}")
-    net = Net(LATENT, "vae", compute=args.dtype)
+    B = args.batch if args.batch > 0 else (LOCAL_BATCH if world == 1 else DP_LOCAL_BATCH)
+    L = args.latent
+    TRAIN_MACS = train_macs(L)
+    note(f"world {world}, backend {backend if world > 1 else '-'}, batch {B}/GPU, latent {L}, {args.dtype}")
+    net = Net(L, "vae", compute=args.dtype)
     net.init_weights(seed=42)                      # same weights on every rank
     # weak scaling: every rank holds its own shard of the synthetic set (N_TRAIN / world maps)
     n_local = max(B, (N_TRAIN // world) // B * B)
@@ -176,11 +206,11 @@ def main():
     nb = n_local // B
     note(f"{n_local} synthetic maps resident per rank")
 
-    def step(i):
+    def step(i, exchange=True):
         xb = x_all[(i % nb) * B:(i % nb + 1) * B]
         # Philox epsilon keyed by the global sample index -> independent of the world size
         net.train_fwd_bwd(xb, None, first_sample=(i * world + rank) * B)
-        if world > 1:
+        if world > 1 and exchange:
             vdist.allreduce_sum_(net.grads)        # one RCCL all-reduce: grads + 3 loss scalars
         net.adam_step(LR, 1.0 / world)
 
@@ -204,7 +234,18 @@ def main():
         dt = float(vdist.allreduce_max_(t).item())
     loss = float(net.grads[net.n_params].item()) / world
     note(f"{args.steps} steps timed: {1e3 * dt / args.steps:.3f} ms/step")
-    attr = None if args.no_attribution else attribution_bench(net, x_all, world)
+    local_ms = None
+    if world > 1:
+        # the same local work without the exchange, on this rank alone: what one GPU does at this batch (the driver's
+        # N=1 line is configs[1] at batch 512, so it is not the equal-work single-GPU number of this line)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, exchange=False)
+        torch.cuda.synchronize()
+        local_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+        dist.barrier()
+    attr = None if args.no_attribution else attribution_bench(net, x_all, world, L)
 
     if rank == 0:
         sps = args.steps * B * world / dt
@@ -213,14 +254,21 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": "configs[1]: models.py VAE train_step, 100k synthetic 40x40 topomaps, "
-                                   f"batch {B}/GPU, latent 28, Adam lr 1e-5, " +
+            "config": {"workload": (f"configs[1]: models.py VAE train_step, 100k synthetic 40x40 topomaps, batch {B}/GPU, "
+                                    if world == 1 else
+                                    f"configs[2]: data-parallel models.py VAE train_step, global batch {B * world} "
+                                    f"({B}/GPU x {world} GPUs; 8192 on 8), one RCCL all-reduce of the flat gradient "
+                                    f"buffer per step, {n_local} synthetic 40x40 topomaps resident per GPU, ") +
+                                   f"latent {L}, Adam lr 1e-5, " +
                                    ("fp32 (exact-f32 MFMA)" if args.dtype == "f32" else
                                     "bf16 MFMA (fp32 accumulate / storage / master weights)"),
-                       "global_batch": B * world, "parallelism": f"dp{world}", "final_loss": loss},
+                       "global_batch": B * world, "local_batch": B, "latent": L, "parallelism": f"dp{world}",
+                       "final_loss": loss},
             "train_tflops": sps * TRAIN_MACS * 2 / 1e12,
             "frac_mfma_peak": sps * TRAIN_MACS * 2 / 1e12 / ((PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else 2500.0) * world),
         }
+        if local_ms is not None:
+            out["local_step_ms_without_allreduce"] = local_ms
         if attr is not None:
             out["attribution"] = attr
         if not args.no_roofline:

@@ -1,0 +1,8 @@
+"""``keras.callbacks.EarlyStopping`` (public path of the class the reference imports from keras.src)."""
+import os as _os, sys as _sys
+_root = _os.path.abspath(__file__)
+for _ in range(3):
+    _root = _os.path.dirname(_root)
+if _root not in _sys.path:
+    _sys.path.insert(0, _root)
+from vae_eeg_xai_amd.keras_compat import EarlyStopping, History  # noqa: F401

@@ -190,8 +190,12 @@ int veex_electrode_readout(const float* maps, const int* pix, const float* minma
  *   scratch: DEVICE, veex_column_quantiles_scratch_bytes(nq, L) bytes.  Exact order statistics by radix select.
  * veex_band_outside_counts: counts[j*nb + k] = #{i : z[i][j] <= lo[j*nb+k] or z[i][j] >= hi[j*nb+k]} with
  *   float64 compares -- the TP (blink rows) / FP (no-blink rows) counters of histogram_25_75 and auc_roc
- *   (analysis.py:255-264,323-333); FN / TN are N minus these.  lo, hi: DEVICE [L][nb] float64. */
+ *   (analysis.py:255-264,323-333); FN / TN are N minus these.  lo, hi: DEVICE [L][nb] float64.
+ * veex_column_medians: np.median(z[:, j]) of every column as NumPy computes it for a float32 column -- the fp32
+ *   mean of the two middle order statistics (the middle one for odd N) -- the value latent masking writes into
+ *   a unit (analysis.py:574-577).  out: DEVICE [L] fp32; scratch: veex_column_quantiles_scratch_bytes(1, L). */
 long long veex_column_quantiles_scratch_bytes(int nq, int L);
+int veex_column_medians(const float* z, int N, int L, float* out, void* scratch, veexStream_t s);
 int veex_column_quantiles(const float* z, int N, int L, const double* q, int nq, double* out, void* scratch,
                           veexStream_t s);
 int veex_band_outside_counts(const float* z, int N, int L, int nb, const double* lo, const double* hi, int* counts,
@@ -207,7 +211,9 @@ void veex_net_destroy(VeexNet* net);
 long long veex_net_param_floats(const VeexNet* net);  /* trainable flat buffer (multiple of 4) */
 long long veex_net_state_floats(const VeexNet* net);  /* BatchNorm moving mean | var */
 int veex_net_num_tensors(const VeexNet* net);
-/* tensor i in Keras get_weights() order (trainable first). offset is into the trainable buffer
+/* tensor i in Keras Model.get_weights() order (train.py:287, analysis.py:127): encoder trainable, encoder
+ * BatchNorm moving statistics, decoder trainable, decoder moving statistics ([KERAS-SEM], parity unpinned; the
+ * metric trackers' scalars Keras appends are not tensors of the net). offset is into the trainable buffer
  * (trainable=1) or the state buffer (trainable=0). For the VAE the two latent heads are stored
  * as one [100][2L] matrix: part = 0 whole tensor, 1 = columns [0,L), 2 = columns [L,2L). */
 int veex_net_tensor_info(const VeexNet* net, int i, char* name, int name_cap, long long* offset, int* ndim,
@@ -227,6 +233,12 @@ int veex_net_set_compute(VeexNet* net, int compute);
  * stream wait for it before returning (fork/join with events the net creates on first use; capturable).
  * NULL (default) = everything on the one stream passed to the call. */
 int veex_net_set_side_stream(VeexNet* net, veexStream_t side);
+
+/* Divisor of the batch-mean loss and of its gradients (models.py:156-163 reduce_mean over the batch).  0 (default):
+ * the batch of the call.  Data parallelism with unequal shards sets global_batch / world on every rank, so that the
+ * SUM all-reduce of the flat gradient buffer followed by veex_adam's gscale = 1/world is the mean over the GLOBAL
+ * batch (no reference call site: the reference is single-process). */
+int veex_net_set_batch_divisor(VeexNet* net, double divisor);
 
 #define VEEX_F_PHILOX 1      /* generate epsilon on device (else read it from the eps argument) */
 #define VEEX_F_ZMEAN_DECODE 2 /* decode z_mean instead of the sampled z (not the reference's VAE.call) */

@@ -54,15 +54,29 @@ def _deconv(x_nchw, W, b, stride, padding):
     return y + b.view(1, -1, 1, 1)
 
 
-def encoder(p, x_nhwc, variant="vae"):
+def _relu(pre_nhwc, masks, layer):
+    """ReLU; with ``masks`` (layer -> NHWC bool array, the device's decisions) the branch is the mask's, so
+    that a comparison with an fp32 implementation is not dominated by the few pre-activations within
+    rounding of the kink (tests/util.device_masks asserts that every disagreement is such a kink)."""
+    if masks is None or layer not in masks:
+        return torch.relu(pre_nhwc)
+    m = torch.as_tensor(masks[layer]).reshape(pre_nhwc.shape).to(pre_nhwc.dtype)
+    return pre_nhwc * m
+
+
+def encoder(p, x_nhwc, variant="vae", masks=None):
     h = x_nhwc.permute(0, 3, 1, 2)
     acts = {}
     for name, cin, cout, k, s, pad in vo.ENC_CONVS:
-        a = torch.relu(_conv_same_s2(h, p[f"enc.{name}.kernel"], p[f"enc.{name}.bias"], s))
-        acts[f"enc.{name}.a"] = a.permute(0, 2, 3, 1)
-        h = _bn(a.permute(0, 2, 3, 1), p, f"enc.{name}").permute(0, 3, 1, 2)
+        pre = _conv_same_s2(h, p[f"enc.{name}.kernel"], p[f"enc.{name}.bias"], s).permute(0, 2, 3, 1)
+        acts[f"enc.{name}.pre"] = pre
+        a = _relu(pre, masks, f"enc.{name}")
+        acts[f"enc.{name}.a"] = a
+        h = _bn(a, p, f"enc.{name}").permute(0, 3, 1, 2)
     flat = h.permute(0, 2, 3, 1).reshape(h.shape[0], -1)
-    d = torch.relu(flat @ p["enc.dense.kernel"] + p["enc.dense.bias"])
+    pre = flat @ p["enc.dense.kernel"] + p["enc.dense.bias"]
+    acts["enc.dense.pre"] = pre
+    d = _relu(pre, masks, "enc.dense")
     acts["enc.dense.a"] = d
     if variant == "vae":
         zm = d @ p["enc.z_mean.kernel"] + p["enc.z_mean.bias"]
@@ -71,24 +85,31 @@ def encoder(p, x_nhwc, variant="vae"):
     return d, None, acts
 
 
-def decoder(p, z):
-    a = torch.relu(z @ p["dec.dense.kernel"] + p["dec.dense.bias"])
+def decoder(p, z, masks=None, acts=None):
+    pre = z @ p["dec.dense.kernel"] + p["dec.dense.bias"]
+    if acts is not None:
+        acts["dec.dense.pre"] = pre
+    a = _relu(pre, masks, "dec.dense")
     h = _bn(a, p, "dec.dense").reshape(-1, 4, 4, 256).permute(0, 3, 1, 2)
     for name, cin, cout, k, s, pad in vo.DEC_DECONVS:
-        pre = _deconv(h, p[f"dec.{name}.kernel"], p[f"dec.{name}.bias"], s, pad)
+        pre = _deconv(h, p[f"dec.{name}.kernel"], p[f"dec.{name}.bias"], s, pad).permute(0, 2, 3, 1)
         if name == "deconv6":
-            return pre.permute(0, 2, 3, 1)            # logits NHWC
-        a = torch.relu(pre)
-        h = _bn(a.permute(0, 2, 3, 1), p, f"dec.{name}").permute(0, 3, 1, 2)
+            return pre                                 # logits NHWC
+        if acts is not None:
+            acts[f"dec.{name}.pre"] = pre
+        a = _relu(pre, masks, f"dec.{name}")
+        h = _bn(a, p, f"dec.{name}").permute(0, 3, 1, 2)
 
 
-def losses(p, x, eps=None, variant="vae"):
-    zm, zlv, _ = encoder(p, x, variant)
+def losses(p, x, eps=None, variant="vae", masks=None, acts=None):
+    zm, zlv, enc_acts = encoder(p, x, variant, masks)
+    if acts is not None:
+        acts.update(enc_acts)
     if variant == "vae":
         z = zm + torch.exp(0.5 * zlv) * eps
     else:
         z = zm
-    logits = decoder(p, z)
+    logits = decoder(p, z, masks, acts)
     bce = torch.clamp(logits, min=0) - logits * x + torch.log1p(torch.exp(-logits.abs()))
     rec = bce.mean(dim=-1).sum(dim=(1, 2)).mean()
     if variant == "vae":
@@ -98,21 +119,35 @@ def losses(p, x, eps=None, variant="vae"):
     return rec + kl, rec, kl, logits
 
 
-def grads(params_np: dict, x_np, eps_np=None, variant="vae", dtype=torch.float64):
+def pre_activations(params_np: dict, x_np, eps_np=None, variant="vae", dtype=torch.float64):
+    """{layer + ".pre": ndarray} of every ReLU layer (what tests/util.device_masks compares the device's
+    ReLU decisions with), plus "logits"."""
+    p = to_torch(params_np, dtype, requires_grad=False)
+    x = torch.tensor(np.asarray(x_np), dtype=dtype)
+    eps = None if eps_np is None else torch.tensor(np.asarray(eps_np), dtype=dtype)
+    acts = {}
+    with torch.no_grad():
+        total, rec, kl, logits = losses(p, x, eps, variant, None, acts)
+    out = {k: v.numpy() for k, v in acts.items() if k.endswith(".pre")}
+    out["logits"] = logits.numpy()
+    return out
+
+
+def grads(params_np: dict, x_np, eps_np=None, variant="vae", dtype=torch.float64, masks=None):
     """Returns (total, rec, kl, {name: grad ndarray}) via autograd."""
     p = to_torch(params_np, dtype)
     x = torch.tensor(np.asarray(x_np), dtype=dtype)
     eps = None if eps_np is None else torch.tensor(np.asarray(eps_np), dtype=dtype)
-    total, rec, kl, logits = losses(p, x, eps, variant)
+    total, rec, kl, logits = losses(p, x, eps, variant, masks)
     names = [k for k, t in p.items() if t.requires_grad]
     gs = torch.autograd.grad(total, [p[k] for k in names])
     return float(total.detach()), float(rec.detach()), float(kl.detach()), {k: g.numpy() for k, g in zip(names, gs)}
 
 
-def saliency(params_np, x_np, units, variant="vae", dtype=torch.float64, grad_x_input=False):
+def saliency(params_np, x_np, units, variant="vae", dtype=torch.float64, grad_x_input=False, masks=None):
     p = to_torch(params_np, dtype, requires_grad=False)
     x = torch.tensor(np.asarray(x_np), dtype=dtype, requires_grad=True)
-    zm, _, _ = encoder(p, x, variant)
+    zm, _, _ = encoder(p, x, variant, masks)
     out = []
     for j in units:
         (g,) = torch.autograd.grad(zm[:, j].sum(), x, retain_graph=True)
@@ -151,7 +186,7 @@ class TorchTrainer:
                 self.m[k].mul_(vo.ADAM_B1).add_(g, alpha=1 - vo.ADAM_B1)
                 self.v[k].mul_(vo.ADAM_B2).addcmul_(g, g, value=1 - vo.ADAM_B2)
                 self.p[k].sub_(alpha * self.m[k] / (self.v[k].sqrt() + vo.ADAM_EPS))
-        return float(total), float(rec), float(kl)
+        return float(total.detach()), float(rec.detach()), float(kl.detach())
 
     def params_numpy(self):
         return {k: t.detach().numpy().copy() for k, t in self.p.items()}

@@ -34,9 +34,9 @@ DEC_DECONVS = [
 ]
 
 
-def param_spec(latent_dim: int, variant: str = "vae"):
-    """Ordered (name, shape, trainable) list in Keras ``get_weights()`` order
-    (all trainable in layer-creation order, then non-trainable) -- SURVEY A.6 [KERAS-SEM]."""
+def _layer_order_spec(latent_dim: int, variant: str = "vae"):
+    """(name, shape, trainable) in layer-creation order, trainable before non-trainable.  init_params
+    draws its random numbers in THIS order (the committed golden fixtures depend on it)."""
     L = latent_dim
     tr, ntr = [], []
 
@@ -71,6 +71,21 @@ def param_spec(latent_dim: int, variant: str = "vae"):
     return [(n, s, True) for n, s in tr] + [(n, s, False) for n, s in ntr]
 
 
+def param_spec(latent_dim: int, variant: str = "vae"):
+    """Ordered (name, shape, trainable) list in Keras ``Model.get_weights()`` order (train.py:287,
+    analysis.py:127) -- SURVEY A.6 [KERAS-SEM], PARITY UNPINNED.  ``Model.weights`` concatenates
+    ``layer.variables`` of the tracked sub-layers (encoder, decoder, then the three metric trackers,
+    models.py:125-133), and a ``Layer``'s variables are its trainable weights in creation order
+    followed by its non-trainable ones: encoder trainable, encoder BN moving statistics, decoder
+    trainable, decoder BN moving statistics.  (The trackers' total/count scalars are not listed.)"""
+    spec = _layer_order_spec(latent_dim, variant)
+    out = []
+    for part in ("enc.", "dec."):
+        out += [t for t in spec if t[0].startswith(part) and t[2]]
+        out += [t for t in spec if t[0].startswith(part) and not t[2]]
+    return out
+
+
 def init_params(latent_dim: int, variant: str = "vae", seed: int = 42, jitter: float = 0.0):
     """Random-init weights of the reference architecture.
 
@@ -82,7 +97,7 @@ def init_params(latent_dim: int, variant: str = "vae", seed: int = 42, jitter: f
     """
     rng = np.random.default_rng(seed)
     p = {}
-    for name, shape, trainable in param_spec(latent_dim, variant):
+    for name, shape, trainable in _layer_order_spec(latent_dim, variant):
         leaf = name.rsplit(".", 1)[1]
         if leaf == "kernel":
             if len(shape) == 4:

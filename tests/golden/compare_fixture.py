@@ -1,0 +1,34 @@
+"""Compare two fixture files key by key: ``python tests/golden/compare_fixture.py got.npz want.npz [rtol]``.
+Used to pin parity: ``got`` from tools/dump_tf_train_step.py (the real TF/Keras reference, run elsewhere),
+``want`` a committed fixture of this repository (made by make_golden.py from the float64 oracle).  Every key
+present in both is compared relative to the max-abs of the wanted array (default 1e-5; gsum.* relative to
+the matching gabs.*)."""
+import sys
+
+import numpy as np
+
+
+def compare(got_path, want_path, rtol=1e-5):
+    got, want = np.load(got_path), np.load(want_path)
+    bad, n = [], 0
+    for k in want.files:
+        if k not in got.files:
+            continue
+        n += 1
+        a, b = np.asarray(got[k], dtype=np.float64), np.asarray(want[k], dtype=np.float64)
+        if a.shape != b.shape:
+            bad.append((k, "shape", a.shape, b.shape))
+            continue
+        scale = float(np.asarray(want["gabs." + k[5:]])) if k.startswith("gsum.") else float(np.abs(b).max())
+        err = float(np.abs(a - b).max()) / (scale + 1e-30)
+        if not err <= rtol:
+            bad.append((k, err))
+    return n, bad
+
+
+if __name__ == "__main__":
+    n, bad = compare(sys.argv[1], sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 1e-5)
+    print(f"{n} keys compared, {len(bad)} outside tolerance")
+    for b in bad:
+        print("  ", b)
+    sys.exit(1 if bad or n == 0 else 0)

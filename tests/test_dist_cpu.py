@@ -30,6 +30,8 @@ def _worker(rank, world, port, out_path):
     x = vo.synth_topomaps(B, 9)
     names = vo.trainable_names(L, "vae")
     assert vdist.world_size() == world and vdist.rank() == rank
+    # the shuffle seed of VAE.fit: rank 0's value on every rank
+    assert vdist.broadcast_int(1234567890123 + rank) == 1234567890123
     lo, hi = vdist.shard_range(B, rank, world)
     # epsilon keyed by the global sample index: the shard draws exactly its slice of the global noise
     eps_full = vo.philox_normal(7, vdist.global_first_sample(0, 0, 1, B), B, L)

@@ -1,0 +1,88 @@
+"""Data parallelism of the PRODUCT path (VAE._step / VAE.fit) on the GPU.
+
+(1) one-process emulation: the "rank 0" and "rank 1" shares of one global batch go through the same
+    VAE._shard_fwd_bwd the distributed step runs; epsilon must be bitwise the full batch's, the summed
+    gradients the full batch's up to the order of fp32 sums -- equal and ragged shards, and a rank
+    without samples;
+(2) two real ranks (torch.distributed.run, gloo, both on the one GPU) run VAE.fit and must reproduce the
+    one-process fit: same history, same weights."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import vae_oracle as vo
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _vae(L, p):
+    from vae_eeg_xai_amd.models import Encoder, Decoder, VAE, Adam
+    v = VAE(Encoder(L), Decoder())
+    v.compile(Adam(1e-5))
+    v._net.set_weights_dict(p)
+    return v
+
+
+@pytest.mark.parametrize("n_global,world", [(64, 2), (37, 2), (5, 4), (3, 4)])
+def test_shards_of_a_global_batch_sum_to_the_full_batch_step(n_global, world):
+    import torch
+    L = 28
+    p = vo.init_params(L, "vae", seed=6, jitter=0.1)
+    x = torch.from_numpy(vo.synth_topomaps(n_global + 11, 8)).cuda()
+    index = torch.from_numpy(np.random.default_rng(0).permutation(n_global + 11)[:n_global]).cuda()
+    full = _vae(L, p)
+    full._net.samples_seen = 1000                       # some earlier global steps
+    full._shard_fwd_bwd(x, None, index, 1, 0)
+    eps_full = full._net.ws_region(n_global, "eps").clone().view(n_global, L)
+    g_full = full._net.grads.clone()
+    total = torch.zeros_like(g_full)
+    from vae_eeg_xai_amd import dist as vdist
+    for r in range(world):
+        rep = _vae(L, p)
+        rep._net.samples_seen = 1000
+        rep._shard_fwd_bwd(x, None, index, world, r)
+        lo, hi = vdist.shard_range(n_global, r, world)
+        if hi > lo:     # the noise a sample sees does not depend on the number of ranks: bitwise
+            eps = rep._net.ws_region(hi - lo, "eps").view(hi - lo, L)
+            assert torch.equal(eps, eps_full[lo:hi]), (r, lo, hi)
+        assert rep._net.samples_seen == 1000 + n_global
+        total += rep._net.grads                         # the SUM all-reduce
+    total /= world                                      # Adam's gscale = 1/world
+    n = full._net.n_params
+    for name, ref in full._net.named_views(g_full):
+        spec = [s for s in full._net.specs if s.name == name][0]
+        got = full._net.view(spec, total)
+        err = (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-30)
+        assert err < 2e-5, (name, err)                  # order of fp32 sums over the batch only
+    assert torch.allclose(total[n:n + 3], g_full[n:n + 3], rtol=2e-6, atol=0)   # the three loss scalars
+
+
+def test_two_rank_fit_reproduces_the_one_process_fit(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dp_worker
+    n, batch, epochs, L, seed, n_val = 101, 32, 2, 8, 5, 21     # ragged last batch (5 -> 3 + 2), ragged validation
+    out = os.path.join(tmp_path, "dp2.npz")
+    env = dict(os.environ, VEEX_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    port = 29600 + os.getpid() % 1000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dp_worker.py"), out,
+           *map(str, (n, batch, epochs, L, seed, n_val))]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    dp = np.load(out)
+    one = dp_worker.run_fit(n, batch, epochs, L, seed, n_val)
+    assert int(dp["samples_seen"]) == int(one["samples_seen"]) == epochs * (n + n_val)
+    for k in one:
+        if k.startswith("h."):
+            assert np.allclose(dp[k], one[k], rtol=2e-5, atol=0), (k, dp[k], one[k])
+    steps = epochs * 4
+    for k in one:
+        if k.startswith("w."):
+            # Adam moves a weight by ~lr per step whatever its gradient: weights whose gradient is at rounding level
+            # may differ by a fraction of those steps; everything else must agree far better
+            d = np.abs(dp[k] - one[k]).max()
+            assert d < 0.5 * steps * 1e-4 + 1e-6 * np.abs(one[k]).max(), (k, d)

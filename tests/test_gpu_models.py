@@ -116,8 +116,42 @@ def test_keras_weight_list_interchange_and_masked_decode(tmp_path):
     for m in (b, c):
         for u, v in zip(ws, m.get_weights()):
             assert np.array_equal(u, v)
+    # the pre-round-2 flat order (all trainable, then all moving statistics) is still accepted, by its shapes
+    specs = a._net.specs
+    flat = [w for s, w in zip(specs, ws) if s.trainable] + [w for s, w in zip(specs, ws) if not s.trainable]
+    assert [w.shape for w in flat] != [w.shape for w in ws]
+    d = VAE(Encoder(L), Decoder())
+    d.set_weights(flat)
+    for u, v in zip(ws, d.get_weights()):
+        assert np.array_equal(u, v)
+    # keras order: encoder trainable (18), encoder moving statistics (6), decoder trainable (26), decoder's (12)
+    assert names[18] == "enc.conv1.mean" and names[24] == "dec.dense.kernel" and names[50] == "dec.dense.mean"
+    for N in (11, 12):       # odd and even N: np.median is the fp32 mean of the two middle elements
+        z = np.random.default_rng(N).standard_normal((N, L)).astype(np.float32)
+        zm = z.copy(); zm[:, 3] = np.median(z[:, 3])
+        assert np.array_equal(np.asarray(a.decode_masked(z, 3)), np.asarray(a.decoder(zm))), N
+    from vae_eeg_xai_amd.latent_stats import column_medians
+    for N in (1, 2, 7, 1000, 4097):
+        z = np.random.default_rng(N).standard_normal((N, L)).astype(np.float32)
+        assert np.array_equal(column_medians(z).cpu().numpy(), np.median(z, axis=0)), N
     z = np.random.default_rng(0).standard_normal((11, L)).astype(np.float32)
-    zm = z.copy(); zm[:, 3] = np.median(z[:, 3])
-    assert np.array_equal(np.asarray(a.decode_masked(z, 3)), np.asarray(a.decoder(zm)))
     zv = z.copy(); zv[:, 0] = 0.25
     assert np.array_equal(np.asarray(a.decode_masked(z, 0, value=0.25)), np.asarray(a.decoder(zv)))
+
+
+def test_device_array_indexes_on_the_device():
+    """analysis.py indexes whole-set outputs per sample (analysis.py:46,581,590): same values as ndarray indexing."""
+    import torch
+    from vae_eeg_xai_amd.models import DeviceArray
+    a = np.random.default_rng(0).standard_normal((9, 4, 3)).astype(np.float32)
+    d = DeviceArray(torch.from_numpy(a).cuda())
+    idx = np.array([3, 0, 8])
+    mask = a[:, 0, 0] > 0
+    for key in (2, -1, slice(1, 7, 2), (slice(None), 1), (3, 2, 1), idx, mask, [1, 2], (idx, 0), (Ellipsis, 2),
+                np.int64(4), slice(None, None, -1)):
+        got, ref = d[key], a[key]
+        assert np.array_equal(got, ref) and np.shape(got) == np.shape(ref), key
+    assert isinstance(d[1, 2, 0], np.float32)
+    with pytest.raises(IndexError):
+        d[9]
+

@@ -4,6 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vae_eeg_xai_amd.net import Net
+from vae_eeg_xai_amd import _lib
 from bench import synth
 var, vals = sys.argv[1], sys.argv[2:]
 B = 4096
@@ -12,7 +13,7 @@ x = torch.from_numpy(synth(B, seed=3)).cuda()
 units = list(range(28))
 for rnd in range(3):
     for v in vals:
-        os.environ[var] = v
+        _lib.setenv(var, v)
         net.attribute(x, units, grad_x_input=True); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(3):

@@ -3,7 +3,7 @@ MFMA GEMM of one train step, in ONE process.  usage: ab_env.py VAR=a,b[,c] [VAR2
 import os, sys, itertools
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from vae_eeg_xai_amd import roofline as rl
+from vae_eeg_xai_amd import roofline as rl, _lib
 
 args = [a for a in sys.argv[1:] if "=" in a]
 only = None
@@ -21,7 +21,7 @@ for label, macs, fn in cases:
     row = []
     for ci, c in enumerate(combos):
         for n, v in zip(names, c):
-            os.environ[n] = v
+            _lib.setenv(n, v)
         t = rl._time_launch(fn, iters=10, warm=2, rounds=3, warm_ms=15.0)
         row.append(t * 1e6)
         tot[ci] += t * 1e6

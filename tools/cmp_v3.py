@@ -34,8 +34,8 @@ def run(name, mode, N, Hin, Cin, Hout, Cout, k, s, pb, aff=0, epi=0, nsplit=1):
         mt = lib.veex_gather_gemm_m_tiles(C.byref(d))
     res = []
     for v, ro in (("0", "0"), ("1", "0"), ("1", "1")):
-        os.environ["VEEX_GGV3"] = v
-        os.environ["VEEX_ROWORD"] = ro   # 1: tiles over (image row, sample, column); skips taps a whole tile pads
+        _lib.setenv("VEEX_GGV3", v)
+        _lib.setenv("VEEX_ROWORD", ro)   # 1: tiles over (image row, sample, column); skips taps a whole tile pads
         out = torch.full((max(nsplit, 1), N, Hout, Hout, Cout), 7.0, device="cuda")
         d.out = out.data_ptr()
         part = None

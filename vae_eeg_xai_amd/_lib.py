@@ -64,6 +64,7 @@ SIGNATURES = {
     "veex_pack_weights_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "veex_net_set_compute": (_I, [_P, _I]),
     "veex_net_set_side_stream": (_I, [_P, _P]),
+    "veex_net_set_batch_divisor": (_I, [_P, _D]),
     "veex_wgrad_gemm": (_I, [C.POINTER(WgradDesc), _P]),
     "veex_wgrad_plan": (_I, [C.POINTER(WgradDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "veex_conv1_fwd": (_I, [_P, _P, _P, _P, _I, _P]),
@@ -89,6 +90,7 @@ SIGNATURES = {
     "veex_electrode_readout": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "veex_column_quantiles_scratch_bytes": (_L, [_I, _I]),
     "veex_column_quantiles": (_I, [_P, _I, _I, C.POINTER(_D), _I, _P, _P, _P]),
+    "veex_column_medians": (_I, [_P, _I, _I, _P, _P, _P]),
     "veex_band_outside_counts": (_I, [_P, _I, _I, _I, _P, _P, _P, _P]),
     "veex_net_create": (_P, [_I, _I]),
     "veex_net_destroy": (None, [_P]),
@@ -126,6 +128,13 @@ def _load():
 
 
 lib = _load()
+
+
+def setenv(name: str, value) -> None:
+    """Flip a tuning switch inside a running process: libveex.so freezes every switch at its
+    first use, so the A/B tools set the variable AND make the library forget its cached values."""
+    os.environ[name] = str(value)
+    lib.veexi_debug_reload_env()
 
 
 def check(rc: int, what: str = "veex call"):

@@ -651,7 +651,7 @@ static int gg_launch_cfg(GGParams& p, int mtiles, bool fast, hipStream_t st) {
   p.gx = ntiles; p.gy = mtiles; p.gz = p.nsplit;
   dim3 grid((unsigned)ntiles * mtiles * p.nsplit, 1, 1);
   if (fast) {
-    static const int want32 = [] { const char* e = getenv("VEEX_BK"); return (e != nullptr && atoi(e) == 32) ? 1 : 0; }();
+    const int want32 = veex_env_int("VEEX_BK", 16) == 32;
     const bool bk32 = want32 && ((p.kh * p.kw == 1) || (p.Cin % 32 == 0));
     const int bk = bk32 ? 32 : 16;
     if (p.nsplit > 1) {
@@ -698,10 +698,12 @@ int veex_gg_bf16_only(const GGParams& p) {
 
 int veex_launch_gather_gemm(const GGParams& pin, hipStream_t st) {
   GGParams p = pin;
-  if (const int tm = veex_env_int("VEEX_TIMING", 0)) {   // timing experiments only (tools/ab_env.py): results are wrong
+#ifdef VEEX_DEBUG_TIMING   // timing experiments only (make TIMING=1; tools/ab_env.py): results are wrong by construction,
+  if (const int tm = veex_env_int("VEEX_TIMING", 0)) {   // so the shipped library does not contain the switch at all
     if (tm & 1) p.a_scale = p.a_shift = nullptr;          //   1: no BatchNorm prologue
     if (tm & 2) { p.epi = VEEX_EPI_RAW; p.partials = nullptr; p.aux = nullptr; }   // 2: plain store epilogue
   }
+#endif
   if (p.stride != 1 && p.stride != 2) { veex_set_error("gather_gemm: stride %d unsupported", p.stride); return -1; }
   if (p.Nb <= 0 || p.Cin <= 0 || p.Cout <= 0 || p.Hout <= 0 || p.Wout <= 0 || p.Hin <= 0 || p.Win <= 0) {
     veex_set_error("gather_gemm: bad geometry"); return -1;

@@ -106,6 +106,19 @@ __global__ void quantile_lerp_kernel(const float* __restrict__ order, const LSLe
   out[i] = v;
 }
 
+// np.median of a float32 column (analysis.py:576): the mean of the two middle order statistics, formed like
+// np.mean of a 2-element float32 array -- fp32 sum, then the division by 2; the middle element itself when N is odd
+__global__ void median_pair_kernel(const float* __restrict__ order, int two, int L, float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= L) return;
+  const float a = order[col];
+  if (!two) { out[col] = a; return; }
+  const float b = order[L + col];
+  const float sum = a + b;
+  out[col] = sum / 2.0f;
+}
+
 // counts[col*nb + k] = #{ i : z[i][col] <= lo[col*nb + k]  or  z[i][col] >= hi[col*nb + k] }   (float64 compares)
 __global__ __launch_bounds__(256) void band_outside_kernel(const float* __restrict__ z, int N, int L, int nb,
                                                            const double* __restrict__ lo, const double* __restrict__ hi,
@@ -165,6 +178,20 @@ int veex_column_quantiles(const float* z, int N, int L, const double* q, int nq,
   hipLaunchKernelGGL(column_select_kernel, dim3(L), dim3(LS_THREADS), 0, st, z, N, L, rk, order);
   VEEX_CHECK_LAUNCH();
   hipLaunchKernelGGL(quantile_lerp_kernel, dim3((nq * L + 255) / 256), dim3(256), 0, st, order, lp, L, out);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+// np.median(z[:, j]) for every column j (NaN-free input): out DEVICE [L] fp32; scratch as for one quantile.
+int veex_column_medians(const float* z, int N, int L, float* out, void* scratch, hipStream_t st) {
+  if (z == nullptr || out == nullptr || scratch == nullptr || N < 1 || L < 1) { veex_set_error("column_medians: bad arguments"); return -1; }
+  LSRanks rk;
+  rk.rank[0] = (N - 1) / 2; rk.rank[1] = N / 2;
+  rk.nr = (rk.rank[0] == rk.rank[1]) ? 1 : 2;
+  float* order = static_cast<float*>(scratch);
+  hipLaunchKernelGGL(column_select_kernel, dim3(L), dim3(LS_THREADS), 0, st, z, N, L, rk, order);
+  VEEX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(median_pair_kernel, dim3((L + 255) / 256), dim3(256), 0, st, order, rk.nr == 2, L, out);
   VEEX_CHECK_LAUNCH();
   return 0;
 }

@@ -9,6 +9,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -24,14 +26,29 @@ void veex_set_error(const char* fmt, ...) {
 }
 extern "C" const char* veex_last_error(void) { return g_err; }
 
-// tuning switches from the environment (read on every call: a handful of getenv per step)
+// Tuning switches from the environment.  Each variable is read ONCE per process, at its first use, and
+// frozen: a change of the environment between veex_net_workspace_floats and the run cannot make the plan and the
+// launch disagree.  The A/B tools flip a switch inside one process through veexi_debug_reload_env().
+struct EnvVal { bool set; int v; };
+static std::mutex g_env_mu;
+static std::map<std::string, EnvVal> g_env;
 int veex_env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return (e != nullptr && *e) ? atoi(e) : dflt;
+  std::lock_guard<std::mutex> lk(g_env_mu);
+  auto it = g_env.find(name);
+  if (it == g_env.end()) {
+    const char* e = getenv(name);
+    EnvVal v; v.set = (e != nullptr && *e); v.v = v.set ? atoi(e) : 0;
+    it = g_env.emplace(name, v).first;
+  }
+  return it->second.set ? it->second.v : dflt;
+}
+extern "C" void veexi_debug_reload_env(void) {
+  std::lock_guard<std::mutex> lk(g_env_mu);
+  g_env.clear();
 }
 extern "C" int veex_abi_version(void) { return 1; }
 
-extern "C" int veexi_loss_finalize(const float*, const float*, const float*, int, float*, float*, float*, hipStream_t);
+extern "C" int veexi_loss_finalize(const float*, const float*, const float*, int, double, float*, float*, float*, hipStream_t);
 extern "C" int veexi_attr_seed(const float*, const float*, float*, int, int, int, int, int, hipStream_t);
 
 #define TRY(x)            \
@@ -153,6 +170,7 @@ struct ConvLayer {  // one Conv2D / Conv2DTranspose / Dense with optional BatchN
 struct VeexNet {
   int L, variant, H1;
   int compute;                  // VEEX_COMPUTE_F32 / VEEX_COMPUTE_BF16
+  double batch_div = 0.0;       // divisor of the batch-mean loss; 0 = the batch of the call (veex_net_set_batch_divisor)
   hipStream_t side = nullptr;   // optional caller-owned second stream for the weight-gradient GEMMs
   mutable hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   mutable int ev_next = 0;      // fork / join events (host objects, created on first use)
@@ -223,7 +241,11 @@ extern "C" VeexNet* veex_net_create(int L, int variant) {
   n->n_params = off;
   n->n_state = 2LL * bnoff;  // mean | var
 
-  // tensor table in Keras get_weights() order: trainable in layer-creation order, then moving stats
+  // Tensor table in Keras Model.get_weights() order ([KERAS-SEM], parity unpinned): Model.weights
+  // concatenates layer.variables of the tracked sub-layers, and a Layer's variables are its trainable weights (layer
+  // creation order) followed by its non-trainable ones -- so: encoder trainable (18 / AE 14), encoder moving
+  // statistics (6), decoder trainable (26), decoder moving statistics (12).  The flat trainable / state buffers
+  // keep their own layout; only this table's order is the interchange order.
   auto add = [&](const std::string& name, long long o, std::initializer_list<long long> shp, int tr, int part = 0) {
     TensorInfo t; t.name = name; t.offset = o; t.ndim = (int)shp.size(); t.trainable = tr; t.part = part;
     int i = 0; for (long long s : shp) t.shape[i++] = s; for (; i < 4; ++i) t.shape[i] = 1;
@@ -232,6 +254,10 @@ extern "C" VeexNet* veex_net_create(int L, int variant) {
   auto add_bn_tr = [&](const ConvLayer& c) {
     add(std::string(c.name) + ".gamma", n->gamma_off + c.bn, {c.bnC}, 1);
     add(std::string(c.name) + ".beta", n->beta_off + c.bn, {c.bnC}, 1);
+  };
+  auto add_bn_st = [&](const ConvLayer& c) {
+    add(std::string(c.name) + ".mean", c.bn, {c.bnC}, 0);
+    add(std::string(c.name) + ".var", (long long)n->n_bn + c.bn, {c.bnC}, 0);
   };
   for (int i = 0; i < 3; ++i) {
     const ConvLayer& c = n->conv[i];
@@ -247,6 +273,7 @@ extern "C" VeexNet* veex_net_create(int L, int variant) {
     add("enc.z_log_var.kernel", n->wh, {100, L}, 1, 2);
     add("enc.z_log_var.bias", n->bh, {L}, 1, 2);
   }
+  for (int i = 0; i < 3; ++i) add_bn_st(n->conv[i]);
   add("dec.dense.kernel", n->ddense.w, {L, 4096}, 1);
   add("dec.dense.bias", n->ddense.b, {4096}, 1);
   add_bn_tr(n->ddense);
@@ -256,11 +283,6 @@ extern "C" VeexNet* veex_net_create(int L, int variant) {
     add(std::string(c.name) + ".bias", c.b, {c.Cout}, 1);
     if (c.bn >= 0) add_bn_tr(c);
   }
-  auto add_bn_st = [&](const ConvLayer& c) {
-    add(std::string(c.name) + ".mean", c.bn, {c.bnC}, 0);
-    add(std::string(c.name) + ".var", (long long)n->n_bn + c.bn, {c.bnC}, 0);
-  };
-  for (int i = 0; i < 3; ++i) add_bn_st(n->conv[i]);
   add_bn_st(n->ddense);
   for (int i = 0; i < 5; ++i) add_bn_st(n->dc[i]);
   return n;
@@ -279,6 +301,11 @@ extern "C" int veex_net_set_side_stream(VeexNet* n, veexStream_t side) {
 extern "C" int veex_net_set_compute(VeexNet* n, int compute) {
   if (n == nullptr || (compute != VEEX_COMPUTE_F32 && compute != VEEX_COMPUTE_BF16)) { veex_set_error("set_compute: bad arguments"); return VEEX_EINVAL; }
   n->compute = compute;
+  return 0;
+}
+extern "C" int veex_net_set_batch_divisor(VeexNet* n, double divisor) {
+  if (n == nullptr || !(divisor >= 0.0) || divisor > 1e12) { veex_set_error("set_batch_divisor: bad arguments"); return VEEX_EINVAL; }
+  n->batch_div = divisor;
   return 0;
 }
 extern "C" long long veex_net_param_floats(const VeexNet* n) { return n ? n->n_params : -1; }
@@ -523,6 +550,9 @@ struct Ctx {
   hipStream_t st;
   long long part_cur = 0;       // bump cursor into scratch.partials: every producer of one pass keeps its own rows
   ColsumBatch fin;              // column-sum finalisations collected during the backward pass (flush_colsum)
+  // divisor of the batch mean (models.py:156-163): the local batch, or the caller's (a rank's share of a global batch)
+  double div() const { return (n->batch_div > 0.0) ? n->batch_div : (double)B; }
+  float inv_div() const { return (n->batch_div > 0.0) ? (float)(1.0 / n->batch_div) : 1.0f / B; }
   const float* scale(int bn) const { return ws + plan.bn_scale + bn; }
   const float* shift(int bn) const { return ws + plan.bn_shift + bn; }
   const float* rstd(int bn) const { return ws + plan.bn_rstd + bn; }
@@ -643,7 +673,7 @@ static int deconv6_forward(Ctx& c, const float* target, float* logits, float* re
                            float* dlsum_b) {
   const VeexNet* n = c.n;
   return veex_deconv6_bce_fwd(c.ws + c.plan.act_dc[4], c.scale(n->dc[4].bn), c.shift(n->dc[4].bn), c.P + n->dc[5].w,
-                              c.P + n->dc[5].b, target, logits, recon, dlogit, rec_b, dlsum_b, c.B, 1.0f / c.B, c.st);
+                              c.P + n->dc[5].b, target, logits, recon, dlogit, rec_b, dlsum_b, c.B, c.inv_div(), c.st);
 }
 
 static hipEvent_t next_event(const VeexNet* n) {
@@ -899,8 +929,8 @@ extern "C" int veex_net_forward(const VeexNet* n, const float* params, const flo
   }
   TRY(decoder_trunk(c, zdec));
   TRY(deconv6_forward(c, x, nullptr, recon, nullptr, ws + P.rec_b, nullptr));
-  return veexi_loss_finalize(ws + P.rec_b, n->variant == VEEX_VARIANT_VAE ? ws + P.kl_b : nullptr, nullptr, B, losses,
-                             metrics, nullptr, st);
+  return veexi_loss_finalize(ws + P.rec_b, n->variant == VEEX_VARIANT_VAE ? ws + P.kl_b : nullptr, nullptr, B, c.div(),
+                             losses, metrics, nullptr, st);
 }
 
 extern "C" int veex_net_train_fwd_bwd(const VeexNet* n, const float* params, const float* state, const float* x,
@@ -921,7 +951,7 @@ extern "C" int veex_net_train_fwd_bwd(const VeexNet* n, const float* params, con
   TRY(encode_impl(c, x, eps_io, flags, seed, first_sample, 1));
   TRY(decoder_trunk(c, ws + P.z));
   TRY(deconv6_forward(c, x, nullptr, nullptr, ws + P.dlogit, ws + P.rec_b, ws + P.dlsum_b));
-  TRY(veexi_loss_finalize(ws + P.rec_b, vae ? ws + P.kl_b : nullptr, ws + P.dlsum_b, B, losses, metrics,
+  TRY(veexi_loss_finalize(ws + P.rec_b, vae ? ws + P.kl_b : nullptr, ws + P.dlsum_b, B, c.div(), losses, metrics,
                           G + n->dc[5].b, st));
 
   // ---- backward (tape.gradient, models.py:166) ----
@@ -977,7 +1007,7 @@ extern "C" int veex_net_train_fwd_bwd(const VeexNet* n, const float* params, con
     TRY(veex_slab_sum(ws + P.slab, p.nsplit, p.slab_stride, p.slab_stride, ws + P.dz, nullptr, 1, 0, st));
   }
   if (vae) {
-    TRY(veex_reparam_kl_bwd(ws + P.dz, ws + P.mulv, ws + P.eps, ws + P.dmulv, B, L, 1.0f / B, st));
+    TRY(veex_reparam_kl_bwd(ws + P.dz, ws + P.mulv, ws + P.eps, ws + P.dmulv, B, L, c.inv_div(), st));
     {  // head biases: column sums of dmulv
       const int chunks = veex_bnrelu_bwd_rows_chunks(B);
       float* part = take_partials(c, (long long)chunks * 3 * 2 * L);

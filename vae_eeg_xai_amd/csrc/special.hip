@@ -750,10 +750,10 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(float* __restrict__ p, 
   }
 }
 
-// losses[0..2] = total, rec, kl (means over the local batch); metrics[0..2] += those, metrics[3] += 1;
+// losses[0..2] = total, rec, kl (sums over the local batch / div; div = the local batch unless the caller set a divisor); metrics[0..2] += those, metrics[3] += 1;
 // db6 = sum_b dlsum_b (bias gradient of deconv6).  Single block.
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ rec_b, const float* __restrict__ kl_b,
-                                                            const float* __restrict__ dlsum_b, int B,
+                                                            const float* __restrict__ dlsum_b, int B, double div,
                                                             float* __restrict__ losses, float* __restrict__ metrics,
                                                             float* __restrict__ db6) {
   __shared__ double red[3 * 4];
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
     s1 = red[0] + red[1] + red[2] + red[3];
     s2 = red[4] + red[5] + red[6] + red[7];
     s3 = red[8] + red[9] + red[10] + red[11];
-    const float rec = (float)(s1 / B), kl = (float)(s2 / B);
+    const float rec = (float)(s1 / div), kl = (float)(s2 / div);
     if (losses != nullptr) { losses[0] = rec + kl; losses[1] = rec; losses[2] = kl; }
     if (metrics != nullptr) { metrics[0] += rec + kl; metrics[1] += rec; metrics[2] += kl; metrics[3] += 1.f; }
     if (db6 != nullptr) db6[0] = (float)s3;
@@ -978,9 +978,9 @@ int veex_adam(float* p, const float* g, float* m, float* v, long long n, int* st
   return 0;
 }
 
-int veexi_loss_finalize(const float* rec_b, const float* kl_b, const float* dlsum_b, int B, float* losses,
+int veexi_loss_finalize(const float* rec_b, const float* kl_b, const float* dlsum_b, int B, double div, float* losses,
                         float* metrics, float* db6, hipStream_t st) {
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, rec_b, kl_b, dlsum_b, B, losses, metrics, db6);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, rec_b, kl_b, dlsum_b, B, div, losses, metrics, db6);
   VEEX_CHECK_LAUNCH();
   return 0;
 }

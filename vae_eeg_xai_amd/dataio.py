@@ -46,10 +46,23 @@ def normalize(x) -> torch.Tensor:
     return out
 
 
-def denormalize(x_normalized, x) -> torch.Tensor:
-    """signal_reconstruction.py:92-95: x_normalized * (max(x) - min(x)) + min(x)."""
+def _extrema(x, minmax_pair) -> torch.Tensor:
+    """(min, max) device pair: ``minmax_pair`` when the caller computed it before (``minmax(x)``), else of ``x``."""
+    if minmax_pair is not None:
+        mm = _dev(minmax_pair).reshape(-1)
+        if mm.numel() != 2:
+            raise ValueError("minmax= expects the 2-element (min, max) pair")
+        return mm
+    if x is None:
+        raise ValueError("give the array the extrema come from, or minmax=")
+    return minmax(x)
+
+
+def denormalize(x_normalized, x=None, *, minmax=None) -> torch.Tensor:
+    """signal_reconstruction.py:92-95: x_normalized * (max(x) - min(x)) + min(x).  ``minmax=`` takes extrema
+    computed earlier (``dataio.minmax(x)``) instead of reducing ``x`` again."""
     tn = _dev(x_normalized)
-    mm = x if (isinstance(x, torch.Tensor) and x.numel() == 2 and x.is_cuda) else minmax(x)
+    mm = _extrema(x, minmax)
     out = torch.empty_like(tn)
     check(lib.veex_denormalize(ptr(tn), ptr(mm), ptr(out), tn.numel(), _lib.current_stream()), "denormalize")
     return out
@@ -83,9 +96,11 @@ def electrode_pixel_table(pos2d, zero_region=(), n_channels: int = 32, map_lengt
     return out
 
 
-def electrode_readout(maps, pixel_table, denormalize_with=None, map_shape: Tuple[int, int] = (40, 40)) -> torch.Tensor:
+def electrode_readout(maps, pixel_table, denormalize_with=None, map_shape: Tuple[int, int] = (40, 40), *,
+                      minmax=None) -> torch.Tensor:
     """indian_functions.py:146-160 for a whole batch: out[b, e] = maps[b][row_e][col_e]
-    (optionally denormalized with the extrema of ``denormalize_with``).  ``maps``: (B,H,W[,1])."""
+    (optionally denormalized with the extrema of the array ``denormalize_with``, or with a (min, max)
+    pair computed earlier passed as ``minmax=``).  ``maps``: (B,H,W[,1])."""
     t = _dev(maps)
     H, W = map_shape
     if t.numel() % (H * W) != 0:
@@ -93,12 +108,12 @@ def electrode_readout(maps, pixel_table, denormalize_with=None, map_shape: Tuple
     B = t.numel() // (H * W)
     tab = np.asarray(pixel_table, dtype=np.int64).reshape(-1, 2)
     if (tab[:, 0] < 0).any() or (tab[:, 0] >= H).any() or (tab[:, 1] < 0).any() or (tab[:, 1] >= W).any():
-        raise IndexError("electrode pixel outside the map")       # the reference would raise IndexError too
+        # stricter than the reference: NumPy would wrap a negative index to the other side of the map
+        raise IndexError("electrode pixel outside the map")
     pix = torch.from_numpy((tab[:, 0] * W + tab[:, 1]).astype(np.int32)).to(t.device)
     mm = None
-    if denormalize_with is not None:
-        d = denormalize_with
-        mm = d if (isinstance(d, torch.Tensor) and d.numel() == 2 and d.is_cuda) else minmax(d)
+    if denormalize_with is not None or minmax is not None:
+        mm = _extrema(denormalize_with, minmax)
     out = torch.empty(B, tab.shape[0], dtype=torch.float32, device=t.device)
     check(lib.veex_electrode_readout(ptr(t), ptr(pix), ptr(mm), ptr(out), B, H * W, tab.shape[0],
                                      _lib.current_stream()), "electrode_readout")

@@ -50,6 +50,16 @@ def allreduce_max_(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def broadcast_int(v: int, src: int = 0) -> int:
+    """Rank ``src``'s integer on every rank (the shuffle seed of ``VAE.fit``)."""
+    if world_size() == 1:
+        return int(v)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([int(v)], dtype=torch.int64, device=dev)
+    dist.broadcast(t, src=src)
+    return int(t.item())
+
+
 def global_first_sample(step: int, r: int, world: int, local_batch: int) -> int:
     """Global index of a rank's first sample at a step: the Philox epsilon counter, so that the
     noise a sample sees does not depend on how many ranks share the batch."""

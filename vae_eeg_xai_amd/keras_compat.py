@@ -39,6 +39,7 @@ class EarlyStopping:
         if cur < self.best - self.min_delta:
             self.best = cur
             self.wait = 0
+            return                      # Keras returns right after an improvement (also with patience=0)
         if self.wait >= self.patience and epoch > 0:
             self.stopped_epoch = epoch
             self.stop_training = True

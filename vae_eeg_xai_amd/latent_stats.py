@@ -38,6 +38,19 @@ def column_quantiles(z, q) -> torch.Tensor:
     return out[0] if scalar else out
 
 
+def column_medians(z) -> torch.Tensor:
+    """``np.median(z[:, j])`` of every column of a float32 (N, L) matrix -> device float32 tensor (L,):
+    the value the reference's latent masking writes into a unit (analysis.py:574-577)."""
+    t = _dev(z)
+    if t.dim() != 2:
+        raise ValueError("column_medians expects an (N, L) matrix")
+    N, L = t.shape
+    out = torch.empty(L, dtype=torch.float32, device=t.device)
+    scratch = torch.empty(lib.veex_column_quantiles_scratch_bytes(1, L), dtype=torch.uint8, device=t.device)
+    check(lib.veex_column_medians(ptr(t), N, L, ptr(out), ptr(scratch), _lib.current_stream()), "column_medians")
+    return out
+
+
 def band_outside_counts(z, lo, hi) -> torch.Tensor:
     """counts[j, k] = #{i : z[i, j] <= lo[j, k] or z[i, j] >= hi[j, k]} (int32, device); lo/hi: (L, nb)."""
     t = _dev(z)

@@ -57,7 +57,14 @@ class DeviceArray:
         return self._t.shape[0]
 
     def __getitem__(self, idx):
-        return self.__array__()[idx]
+        # index in HBM and move only the selection (analysis.py indexes whole-set outputs per sample in Python
+        # loops, e.g. :46,:581: copying the set per index would be O(N^2) bytes)
+        try:
+            t = self._t[_device_index(idx, self._t.device)]
+        except (TypeError, ValueError, RuntimeError):
+            return self.__array__()[idx]          # index forms torch lacks (negative strides, ...)
+        a = t.detach().cpu().numpy()
+        return a[()] if a.ndim == 0 else a
 
     def __iter__(self):
         return iter(self.__array__())
@@ -72,6 +79,24 @@ class DeviceArray:
         return f"DeviceArray(shape={self.shape}, device={self._t.device})"
 
 
+def _device_index(idx, device):
+    """NumPy-style index -> torch index with array parts moved to the device."""
+    if isinstance(idx, tuple):
+        return tuple(_device_index(i, device) for i in idx)
+    if isinstance(idx, DeviceArray):
+        idx = idx._t
+    if isinstance(idx, torch.Tensor):
+        return idx.to(device)
+    if isinstance(idx, (list, np.ndarray)):
+        a = np.asarray(idx)
+        if a.dtype != np.bool_:
+            a = a.astype(np.int64)
+        return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    if isinstance(idx, np.integer):
+        return int(idx)
+    return idx
+
+
 def _host_rng_eps(shape, generator):
     if generator is None:
         return None
@@ -82,24 +107,27 @@ def _host_rng_eps(shape, generator):
 
 def sample(z_mean, z_log_var, epsilon=None, generator=None):
     """Reparameterisation trick (reference models.py:10-22): z = mean + exp(0.5*log_var) * eps.
-    Runs the fused HIP reparameterisation kernel; ``epsilon`` (B,L) injects the noise."""
+    Runs the fused HIP reparameterisation kernel; ``epsilon`` (B,L) injects the noise.  With torch tensors
+    that require grad the result is differentiable (torch.ops.veex.sample has a registered backward)."""
     from . import _lib
     from ._lib import lib, check, ptr
-    zm = _as_device_f32(z_mean, torch.device("cuda", torch.cuda.current_device()))
-    zlv = _as_device_f32(z_log_var, zm.device)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    keep_graph = any(isinstance(t, torch.Tensor) and t.requires_grad for t in (z_mean, z_log_var))
+    zm = z_mean.to(dev) if keep_graph else _as_device_f32(z_mean, dev)
+    zlv = z_log_var.to(dev) if keep_graph else _as_device_f32(z_log_var, dev)
     B, L = zm.shape
     if epsilon is None:
         epsilon = _host_rng_eps((B, L), generator)
-    mulv = torch.cat([zm, zlv], dim=1).contiguous()
-    z = torch.empty_like(zm)
-    if epsilon is None:
-        eps = torch.empty_like(zm)
+    if epsilon is None:      # unseeded like the reference's tf.random.normal: Philox with a fresh seed
+        eps = torch.empty(B, L, dtype=torch.float32, device=dev)
         seed = int(np.random.SeedSequence().entropy % (1 << 63))
-        check(lib.veex_reparam_kl_fwd(ptr(mulv), ptr(eps), ptr(z), None, B, L, 1, seed, 0, _lib.current_stream()))
+        mulv = torch.cat([zm.detach(), zlv.detach()], dim=1).contiguous()
+        scratch = torch.empty_like(eps)
+        check(lib.veex_reparam_kl_fwd(ptr(mulv), ptr(eps), ptr(scratch), None, B, L, 1, seed, 0, _lib.current_stream()))
     else:
-        eps = _as_device_f32(epsilon, zm.device)
-        check(lib.veex_reparam_kl_fwd(ptr(mulv), ptr(eps), ptr(z), None, B, L, 0, 0, 0, _lib.current_stream()))
-    return DeviceArray(z)
+        eps = _as_device_f32(epsilon, dev)
+    z = torch.ops.veex.sample(zm, zlv, eps)
+    return z if keep_graph else DeviceArray(z)
 
 
 class _LayerHandle:
@@ -233,7 +261,8 @@ class VAE:
     __call__ = call
 
     def train_step(self, data, epsilon=None):
-        """One optimisation step (reference models.py:148-180); returns the running means."""
+        """One optimisation step (reference models.py:148-180); returns the running means.  Under
+        torch.distributed every rank passes the same (global) batch and works on its own slice of it."""
         x, _labels = data
         self._step(x, epsilon)
         return self._logs()
@@ -243,19 +272,75 @@ class VAE:
         self._net.forward(x, epsilon, want_recon=False, accumulate_metrics=True)
         return self._logs()
 
-    def _step(self, x, epsilon=None, first_sample=None):
+    def _step(self, x, epsilon=None, index=None):
+        """One optimisation step on a GLOBAL batch: ``x`` itself, or rows ``index`` (device int64) of the
+        resident set ``x``.  Data parallelism: rank r takes the contiguous slice
+        ``shard_range(n_global, r, world)``; the Philox epsilon of a sample is keyed by its global index
+        (``samples_seen`` counts GLOBAL samples on every rank), and the loss is divided by
+        ``n_global / world`` so that ONE sum all-reduce of the flat gradient buffer followed by Adam's
+        1/world is the mean over the global batch (models.py:156-163) for any shard sizes, empty ones
+        included.  With one process this is the plain step."""
         net = self._net
-        world = vdist.world_size()
-        net.train_fwd_bwd(x, epsilon, accumulate_metrics=(world == 1), first_sample=first_sample)
+        world, rank = vdist.world_size(), vdist.rank()
+        self._shard_fwd_bwd(x, epsilon, index, world, rank)
         if world > 1:
-            vdist.allreduce_sum_(net.grads)        # gradients and the 3 loss scalars in one collective
+            vdist.allreduce_sum_(net.grads)            # gradients and the 3 loss scalars in one collective
             net.metrics[:3] += net.grads[net.n_params:net.n_params + 3] / world
             net.metrics[3] += 1.0
         net.adam_step(self._lr(), 1.0 / world)
 
+    def _shard_fwd_bwd(self, x, epsilon, index, world, rank):
+        """Rank ``rank``'s share of one global step: its slice of the batch through
+        veex_net_train_fwd_bwd, gradients (already divided for the GLOBAL mean) into ``net.grads``."""
+        net = self._net
+        n_global = int(index.shape[0]) if index is not None else int(x.shape[0])
+        lo, hi = vdist.shard_range(n_global, rank, world)
+        first = net.samples_seen + lo
+        net.samples_seen += n_global
+        if world == 1:
+            xb = x if index is None else x.index_select(0, index)
+            net.train_fwd_bwd(xb, epsilon, accumulate_metrics=True, first_sample=first)
+            return
+        if hi == lo:
+            net.grads.zero_()                          # more ranks than samples: contribute nothing, still reduce
+            return
+        xb = x[lo:hi] if index is None else x.index_select(0, index[lo:hi])
+        eb = None if epsilon is None else epsilon[lo:hi]
+        net.set_batch_divisor(n_global / world)
+        try:
+            net.train_fwd_bwd(xb, eb, accumulate_metrics=False, first_sample=first)
+        finally:
+            net.set_batch_divisor(0.0)
+
+    def _validate(self, xv, batch_size):
+        """test_step over the validation set (models.py:182-207), sharded like the training batches; the
+        four metric accumulators are summed over ranks once at the end, so every rank logs the same values
+        (and EarlyStopping stops all ranks in the same epoch)."""
+        net = self._net
+        world, rank = vdist.world_size(), vdist.rank()
+        net.metrics.zero_()
+        for s in range(0, xv.shape[0], batch_size):
+            n_global = min(batch_size, xv.shape[0] - s)
+            lo, hi = vdist.shard_range(n_global, rank, world)
+            first = net.samples_seen + lo
+            net.samples_seen += n_global
+            if world == 1:
+                net.forward(xv[s:s + n_global], None, want_recon=False, accumulate_metrics=True, first_sample=first)
+            elif hi > lo:
+                net.set_batch_divisor(n_global / world)
+                try:
+                    net.forward(xv[s + lo:s + hi], None, want_recon=False, accumulate_metrics=True, first_sample=first)
+                finally:
+                    net.set_batch_divisor(0.0)
+            else:
+                net.metrics[3] += 1.0
+        if world > 1:
+            vdist.allreduce_sum_(net.metrics)
+            net.metrics /= world
+
     def train_on_batch(self, x, y=None):
         self._net.metrics.zero_()
-        self._step(x)
+        self._step(_as_device_f32(x, self._net.device))
         logs = self._logs()
         return [logs[k] for k in self._metric_names]
 
@@ -264,10 +349,12 @@ class VAE:
         """keras Model.fit as the reference calls it (train.py:141-142,196-197): positional
         (x, y, batch_size, epochs); y is ignored (train_step unpacks and drops it); shuffles every
         epoch, keeps the last partial batch, logs the unweighted running mean over batches.
-        Under torch.distributed every rank takes its slice of each global batch."""
+        Under torch.distributed ``batch_size`` is the GLOBAL batch: all ranks walk the same permutation
+        (rank 0's seed is broadcast when ``seed`` is None) and each takes its slice of every batch, the
+        ragged last one included (see _step)."""
         net = self._net
         batch_size = int(batch_size or 32)
-        world, rank = vdist.world_size(), vdist.rank()
+        world = vdist.world_size()
         xd = _as_device_f32(x, net.device)
         N = xd.shape[0]
         xv = None
@@ -278,6 +365,8 @@ class VAE:
             if hasattr(cb, "on_train_begin"):
                 cb.on_train_begin()
         hist = History()
+        if world > 1:
+            seed = vdist.broadcast_int(int(np.random.SeedSequence().entropy % (1 << 62)) if seed is None else int(seed))
         rng = np.random.default_rng(seed)
         self.stop_training = False
         for epoch in range(int(epochs)):
@@ -285,22 +374,13 @@ class VAE:
             perm_d = torch.from_numpy(perm).to(net.device)
             net.metrics.zero_()
             for s in range(0, N, batch_size):
-                idx = perm_d[s:s + batch_size]
-                if world > 1:
-                    lo, hi = vdist.shard_range(idx.shape[0], rank, world)
-                    idx = idx[lo:hi]
-                    if idx.numel() == 0:
-                        raise ValueError("global batch smaller than the world size")
-                xb = xd.index_select(0, idx)
-                self._step(xb)
+                self._step(xd, None, index=perm_d[s:s + batch_size])
             logs = self._logs()
             if xv is not None:
-                net.metrics.zero_()
-                for s in range(0, xv.shape[0], batch_size):
-                    net.forward(xv[s:s + batch_size], None, want_recon=False, accumulate_metrics=True)
+                self._validate(xv, batch_size)
                 logs.update(self._logs("val_"))
             hist.append(epoch, logs)
-            if verbose:
+            if verbose and vdist.rank() == 0:
                 print(f"Epoch {epoch + 1}/{epochs} - " + " - ".join(f"{k}: {v:.4f}" for k, v in logs.items()))
             for cb in callbacks:
                 if hasattr(cb, "on_epoch_end"):
@@ -368,12 +448,15 @@ class VAE:
         """Latent masking of the reference's analysis (analysis.py:574-581): overwrite latent unit
         ``unit`` of every row of ``z`` with its median over the set (np.median semantics) or with
         ``value``, then decode.  Everything stays on the device."""
+        from .latent_stats import column_medians
         zt = _as_device_f32(z, self._net.device).clone()
         j = int(unit)
         if not 0 <= j < zt.shape[1]:
             raise IndexError(f"latent unit {j} out of range")
-        v = torch.quantile(zt[:, j], 0.5) if (isinstance(value, str) and value == "median") else float(value)
-        zt[:, j] = v
+        if isinstance(value, str) and value == "median":
+            zt[:, j] = column_medians(zt)[j]          # radix-select kernel; (a + b) / 2 in fp32 like np.median
+        else:
+            zt[:, j] = float(value)
         return DeviceArray(self._net.decode(zt))
 
     def save_weights(self, filepath, save_format=None, **kwargs):

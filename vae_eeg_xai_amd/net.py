@@ -2,8 +2,9 @@
 
 ``Net`` owns the flat fp32 buffers in HBM (trainable parameters, gradients, Adam moments,
 BatchNorm moving statistics, workspace) as torch tensors and hands raw pointers + the current
-HIP stream to the C-ABI (include/veex.h).  torch is plumbing only (memory, streams,
-torch.distributed); every arithmetic op of the hot path runs in the HIP library.
+HIP stream to the C-ABI (include/veex.h) through the custom ops of ops.py (torch.ops.veex.*).  torch is
+plumbing only (memory, streams, dispatcher, torch.distributed); every arithmetic op of the hot path
+runs in the HIP library.
 """
 from __future__ import annotations
 
@@ -15,6 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import ops as _ops  # noqa: F401  (registers torch.ops.veex.*)
 from ._lib import lib, check, ptr
 
 ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-7   # keras legacy Adam defaults (train.py:9,137)
@@ -79,6 +81,9 @@ class Net:
             self.metrics = torch.zeros(4, dtype=torch.float32, device=self.device)
         self.philox_seed = 42
         self.samples_seen = 0
+        # the whole-step calls go through torch.ops.veex.* (ops.py: custom ops whose bodies are the ctypes
+        # calls); VEEX_DIRECT_CTYPES=1 binds the C-ABI directly (same kernels; for measuring the dispatcher)
+        self.via_ops = os.environ.get("VEEX_DIRECT_CTYPES", "0") != "1"
         self.reset_bn_state()
 
     def __del__(self):
@@ -164,17 +169,36 @@ class Net:
         return {n: v.detach().cpu().numpy().copy() for n, v in self.named_views(buf)}
 
     def get_weights(self) -> List[np.ndarray]:
-        """keras Model.get_weights() order: trainable (layer creation order) then non-trainable."""
+        """keras Model.get_weights() order ([KERAS-SEM], parity unpinned): encoder trainable,
+        encoder moving statistics, decoder trainable, decoder moving statistics."""
         return [self.view(s).detach().cpu().numpy().copy() for s in self.specs]
+
+    def _weight_orders(self):
+        """The get_weights() order, and the flat "all trainable, then all moving statistics" order this
+        package wrote before round 2 (lists saved then still load)."""
+        keras = list(self.specs)
+        flat = [s for s in self.specs if s.trainable] + [s for s in self.specs if not s.trainable]
+        return [keras, flat]
 
     def set_weights(self, ws: Sequence[np.ndarray]):
         if len(ws) != len(self.specs):
             raise ValueError(f"expected {len(self.specs)} arrays, got {len(ws)}")
-        for s, w in zip(self.specs, ws):
-            w = np.asarray(w, dtype=np.float32)
-            if tuple(w.shape) != tuple(s.shape):
-                raise ValueError(f"{s.name}: shape {w.shape} != {s.shape}")
-            self.view(s).copy_(torch.from_numpy(np.ascontiguousarray(w)))
+        arrs = [np.asarray(w, dtype=np.float32) for w in ws]
+        shapes = [tuple(a.shape) for a in arrs]
+        for order in self._weight_orders():      # accepted by the sequence of shapes
+            if shapes == [tuple(s.shape) for s in order]:
+                for s, w in zip(order, arrs):
+                    self.view(s).copy_(torch.from_numpy(np.ascontiguousarray(w)))
+                return
+        for s, shp in zip(self.specs, shapes):
+            if shp != tuple(s.shape):
+                raise ValueError(f"{s.name}: shape {shp} != {s.shape}")
+
+    def set_batch_divisor(self, divisor: float = 0.0):
+        """Divisor of the batch-mean loss and its gradients; 0 = the batch of the call.  A rank that holds
+        ``n_local`` of ``n_global`` samples sets ``n_global / world``: SUM all-reduce + Adam's 1/world is
+        then the mean over the global batch whatever the shard sizes (models.py:156-163)."""
+        check(lib.veex_net_set_batch_divisor(self._h, float(divisor)), "net_set_batch_divisor")
 
     # ---------------- workspace ----------------
     def workspace(self, batch: int) -> torch.Tensor:
@@ -223,17 +247,20 @@ class Net:
         B, L = x.shape[0], self.latent_dim
         ws = self.workspace(B)
         e, flags = self._eps_args(eps, B)
-        z = torch.empty(B, L, dtype=torch.float32, device=self.device)
-        zm = zlv = None
-        if self.variant == "vae":
-            zm, zlv = torch.empty_like(z), torch.empty_like(z)
         first = self.samples_seen
         if flags & _lib.F_PHILOX:
             self.samples_seen += B
-        check(lib.veex_net_encode(self._h, ptr(self.params), ptr(self.state), ptr(x), ptr(e), B, flags,
-                                  self.philox_seed, first, ptr(ws), ws.numel(), ptr(zm), ptr(zlv), ptr(z),
-                                  _lib.current_stream()), "net_encode")
-        return (zm, zlv, z) if self.variant == "vae" else (z, None, z)
+        vae = self.variant == "vae"
+        if self.via_ops:
+            zm, zlv, z = torch.ops.veex.encode(self._h, self.params, self.state, x, e, flags, self.philox_seed, first,
+                                               ws, L, vae)
+        else:
+            z = torch.empty(B, L, dtype=torch.float32, device=self.device)
+            zm, zlv = (torch.empty_like(z), torch.empty_like(z)) if vae else (None, None)
+            check(lib.veex_net_encode(self._h, ptr(self.params), ptr(self.state), ptr(x), ptr(e), B, flags,
+                                      self.philox_seed, first, ptr(ws), ws.numel(), ptr(zm), ptr(zlv), ptr(z),
+                                      _lib.current_stream()), "net_encode")
+        return (zm, zlv, z) if vae else (z, None, z)
 
     def decode(self, z, want_logits=False):
         z = _as_device_f32(z, self.device)
@@ -241,13 +268,17 @@ class Net:
             raise ValueError(f"expected (B,{self.latent_dim}) latent, got {tuple(z.shape)}")
         B = z.shape[0]
         ws = self.workspace(B)
-        recon = torch.empty(B, 40, 40, 1, dtype=torch.float32, device=self.device)
-        logits = torch.empty_like(recon) if want_logits else None
-        check(lib.veex_net_decode(self._h, ptr(self.params), ptr(self.state), ptr(z), B, ptr(ws), ws.numel(),
-                                  ptr(recon), ptr(logits), _lib.current_stream()), "net_decode")
+        if self.via_ops:
+            recon, logits = torch.ops.veex.decode(self._h, self.params, self.state, z, ws, bool(want_logits))
+        else:
+            recon = torch.empty(B, 40, 40, 1, dtype=torch.float32, device=self.device)
+            logits = torch.empty_like(recon) if want_logits else None
+            check(lib.veex_net_decode(self._h, ptr(self.params), ptr(self.state), ptr(z), B, ptr(ws), ws.numel(),
+                                      ptr(recon), ptr(logits), _lib.current_stream()), "net_decode")
         return (recon, logits) if want_logits else recon
 
-    def forward(self, x, eps=None, want_recon=True, accumulate_metrics=False, zmean_decode=False):
+    def forward(self, x, eps=None, want_recon=True, accumulate_metrics=False, zmean_decode=False,
+                first_sample: Optional[int] = None):
         """VAE.call + losses (test_step): returns (recon or None, losses[3] device tensor)."""
         x = self._x(x)
         B = x.shape[0]
@@ -255,15 +286,21 @@ class Net:
         e, flags = self._eps_args(eps, B)
         if zmean_decode:
             flags |= _lib.F_ZMEAN_DECODE
+        first = first_sample
+        if first is None:
+            first = self.samples_seen
+            if flags & _lib.F_PHILOX:
+                self.samples_seen += B
+        metrics = self.metrics if accumulate_metrics else None
+        if self.via_ops:
+            recon, losses = torch.ops.veex.forward(self._h, self.params, self.state, x, e, flags, self.philox_seed,
+                                                   first, ws, metrics, bool(want_recon))
+            return (recon if want_recon else None), losses
         recon = torch.empty(B, 40, 40, 1, dtype=torch.float32, device=self.device) if want_recon else None
         losses = torch.empty(3, dtype=torch.float32, device=self.device)
-        first = self.samples_seen
-        if flags & _lib.F_PHILOX:
-            self.samples_seen += B
         check(lib.veex_net_forward(self._h, ptr(self.params), ptr(self.state), ptr(x), ptr(e), B, flags,
                                    self.philox_seed, first, ptr(ws), ws.numel(), ptr(recon), ptr(losses),
-                                   ptr(self.metrics) if accumulate_metrics else None, _lib.current_stream()),
-              "net_forward")
+                                   ptr(metrics), _lib.current_stream()), "net_forward")
         return recon, losses
 
     def train_fwd_bwd(self, x, eps=None, accumulate_metrics=True, first_sample: Optional[int] = None):
@@ -278,14 +315,22 @@ class Net:
             if flags & _lib.F_PHILOX:
                 self.samples_seen += B
         losses = self.grads[self.n_params:self.n_params + 3]
+        metrics = self.metrics if accumulate_metrics else None
+        if self.via_ops:
+            torch.ops.veex.train_fwd_bwd(self._h, self.params, self.state, x, e, flags, self.philox_seed,
+                                         first_sample, ws, self.grads, metrics)
+            return losses
         check(lib.veex_net_train_fwd_bwd(self._h, ptr(self.params), ptr(self.state), ptr(x), ptr(e), B, flags,
                                          self.philox_seed, first_sample, ptr(ws), ws.numel(), ptr(self.grads),
-                                         ptr(losses), ptr(self.metrics) if accumulate_metrics else None,
-                                         _lib.current_stream()), "net_train_fwd_bwd")
+                                         ptr(losses), ptr(metrics), _lib.current_stream()), "net_train_fwd_bwd")
         return losses
 
     def adam_step(self, lr: float, grad_scale: float = 1.0):
         """optimizer.apply_gradients (models.py:169) with keras legacy Adam."""
+        if self.via_ops:
+            torch.ops.veex.adam(self.params, self.grads[:self.n_params], self.adam_m, self.adam_v, self.adam_step_count,
+                                self.adam_alpha, float(lr), float(grad_scale), ADAM_B1, ADAM_B2, ADAM_EPS)
+            return
         check(lib.veex_adam(ptr(self.params), ptr(self.grads), ptr(self.adam_m), ptr(self.adam_v), self.n_params,
                             ptr(self.adam_step_count), ptr(self.adam_alpha), float(lr), float(grad_scale),
                             ADAM_B1, ADAM_B2, ADAM_EPS, _lib.current_stream()), "adam")
@@ -296,6 +341,8 @@ class Net:
         B = x.shape[0]
         units = [int(u) for u in units]
         ws = self.workspace(B)
+        if self.via_ops:
+            return torch.ops.veex.attribute(self._h, self.params, self.state, x, units, bool(grad_x_input), ws)
         out = torch.empty(len(units), B, 40, 40, dtype=torch.float32, device=self.device)
         arr = (C.c_int * len(units))(*units)
         check(lib.veex_net_attribute(self._h, ptr(self.params), ptr(self.state), ptr(x), B, arr, len(units),

@@ -187,12 +187,12 @@ _PMC_NOTE = ("HBM bytes per launch (read + write) from separate rocprofv3 --pmc 
              "(tools/run_profiles.sh, batch 512; FETCH_SIZE doubled per the gfx950 correction), profiles/*_pmc_gemms.json")
 
 
-def _pmc_traffic(label):
+def _pmc_traffic(label, bf16=False):
     """Per-launch HBM traffic of a GEMM from the newest committed PMC summary (counters cannot be
     collected inside bench.py: they need rocprofv3 passes of their own)."""
     import glob, json, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc_gemms.json")))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc_gemms_bf16.json" if bf16 else "r*_pmc_gemms.json")))
     if not files:
         return None
     try:
@@ -213,9 +213,8 @@ def dominant_kernel_roofline(net, batch):
             continue
         t = _time_launch(fn, iters=20, warm=3)
         tf = 2.0 * macs / t / 1e12
-        traffic = _pmc_traffic("dec.deconv4.fwd")
-        if bf16:
-            traffic = None   # PMC passes of the bf16 kernels: profiles/*_pmc_gemms_bf16.json when collected
+        # the committed counter passes were taken at batch 512 (tools/run_profiles.sh)
+        traffic = _pmc_traffic("dec.deconv4.fwd", bf16) if batch == 512 else None
         best = {"bound": "mfma", "kernel": ("gather_gemm_bf16_kernel" if bf16 else "gather_gemm_v3_kernel") +
                 " mode 1 (dec.deconv4 forward, Conv2DTranspose 128->64 k3 s1)",
                 "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
