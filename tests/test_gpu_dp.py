@@ -61,28 +61,36 @@ def test_shards_of_a_global_batch_sum_to_the_full_batch_step(n_global, world):
     assert torch.allclose(total[n:n + 3], g_full[n:n + 3], rtol=2e-6, atol=0)   # the three loss scalars
 
 
-def test_two_rank_fit_reproduces_the_one_process_fit(tmp_path):
+@pytest.mark.parametrize("lr", [0.0, 1e-4])
+def test_two_rank_fit_reproduces_the_one_process_fit(tmp_path, lr):
+    """lr = 0: the weights stand still, so every logged metric of both epochs (training and validation, ragged
+    batches included) must agree to the order of fp32 sums -- epsilon indexing, sharding, loss weighting and the
+    metric means are all in it.  lr = 1e-4: the optimizer runs; Adam turns a rounding-level gradient into a step of
+    ~lr whatever its size (sign-like in its first steps), so weights are compared to a fraction of the steps taken
+    and the metrics relative to the total loss."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import dp_worker
     n, batch, epochs, L, seed, n_val = 101, 32, 2, 8, 5, 21     # ragged last batch (5 -> 3 + 2), ragged validation
     out = os.path.join(tmp_path, "dp2.npz")
     env = dict(os.environ, VEEX_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    port = 29600 + os.getpid() % 1000
+    port = 29600 + os.getpid() % 1000 + (7 if lr else 0)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dp_worker.py"), out,
-           *map(str, (n, batch, epochs, L, seed, n_val))]
+           *map(str, (n, batch, epochs, L, seed, n_val, lr))]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     dp = np.load(out)
-    one = dp_worker.run_fit(n, batch, epochs, L, seed, n_val)
+    one = dp_worker.run_fit(n, batch, epochs, L, seed, n_val, lr)
     assert int(dp["samples_seen"]) == int(one["samples_seen"]) == epochs * (n + n_val)
+    total = np.abs(one["h.loss"]).max()
     for k in one:
         if k.startswith("h."):
-            assert np.allclose(dp[k], one[k], rtol=2e-5, atol=0), (k, dp[k], one[k])
+            if lr == 0.0:
+                assert np.allclose(dp[k], one[k], rtol=1e-5, atol=0), (k, dp[k], one[k])
+            else:
+                assert np.abs(dp[k] - one[k]).max() < 2e-5 * total, (k, dp[k], one[k])
     steps = epochs * 4
     for k in one:
         if k.startswith("w."):
-            # Adam moves a weight by ~lr per step whatever its gradient: weights whose gradient is at rounding level
-            # may differ by a fraction of those steps; everything else must agree far better
             d = np.abs(dp[k] - one[k]).max()
-            assert d < 0.5 * steps * 1e-4 + 1e-6 * np.abs(one[k]).max(), (k, d)
+            assert d <= 0.5 * steps * lr + 1e-6 * np.abs(one[k]).max() * (lr > 0), (k, d)
