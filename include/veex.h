@@ -177,6 +177,14 @@ int veex_adam(float* p, const float* g, float* m, float* v, long long n, int* st
  * (pix[e] = row*width + col; the host validates 0 <= pix[e] < map_elems). */
 int veex_minmax_partial_blocks(long long n);
 int veex_minmax(const float* x, long long n, float* partials, float* minmax, veexStream_t s);
+/* veex_minmax for callers that cannot allocate -- code under HIP-graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc.  It has no counterpart in the reference (whose NumPy min/max allocate freely).  Same
+ * kernels and bit-identical result as veex_minmax; the per-block partials live in a 16 KB file-scope device array of
+ * the library (one copy per GPU, held until the process ends) instead of a caller buffer.  Limits: n <= 2^32
+ * floats per call (larger n is rejected with VEEX_EINVAL); calls that overlap on ONE GPU (different streams) share
+ * the array and race -- serialise them; the first call on a device resolves the array's address and must not be
+ * made under stream capture.  Calls no hipMalloc / hipFree. */
+int veex_minmax_static(const float* x, long long n, float* minmax, veexStream_t s);
 int veex_normalize(const float* x, const float* minmax, float* out, long long n, veexStream_t s);
 int veex_denormalize(const float* x, const float* minmax, float* out, long long n, veexStream_t s);
 int veex_electrode_readout(const float* maps, const int* pix, const float* minmax, float* out, int batch,

@@ -85,6 +85,7 @@ SIGNATURES = {
     "veex_adam": (_I, [_P, _P, _P, _P, _L, _P, _P, _D, _D, _D, _D, _D, _P]),
     "veex_minmax_partial_blocks": (_I, [_L]),
     "veex_minmax": (_I, [_P, _L, _P, _P, _P]),
+    "veex_minmax_static": (_I, [_P, _L, _P, _P]),
     "veex_normalize": (_I, [_P, _P, _P, _L, _P]),
     "veex_denormalize": (_I, [_P, _P, _P, _L, _P]),
     "veex_electrode_readout": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

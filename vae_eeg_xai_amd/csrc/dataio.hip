@@ -6,6 +6,7 @@
 // add -- no FMA contraction), so results are bit-identical to NumPy float32.
 #include "veex_internal.h"
 #include <float.h>
+#include <mutex>
 
 #pragma clang fp contract(off)
 
@@ -124,6 +125,50 @@ int veex_minmax(const float* x, long long n, float* partials, float* minmax, hip
   const int blocks = veex_minmax_partial_blocks(n);
   hipLaunchKernelGGL(minmax_partial_kernel, dim3(blocks), dim3(256), 0, st, x, n, partials);
   hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(256), 0, st, partials, blocks, minmax);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"
+
+// ---- veex_minmax for callers that cannot allocate (HIP-graph capture, tight serving loops): the per-block partials
+// live in a file-scope device array instead of a caller-provided buffer.  16 KB per GPU, held until the process
+// ends.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU (different streams) race.
+// Nothing has to start at zero: pass 1 overwrites partial rows [0, blocks), pass 2 reads exactly those.
+#define VEEX_MINMAX_STATIC_BLOCKS 2048                 /* = the cap of veex_minmax_partial_blocks */
+#define VEEX_MINMAX_STATIC_MAX_ELEMS (1LL << 32)       /* stated limit: 2^32 floats (16 GiB) per call */
+#define VEEX_MAX_DEVICES 64
+static __device__ __align__(256) float scratch[2 * VEEX_MINMAX_STATIC_BLOCKS];
+static std::mutex g_scratch_mu;
+static float* g_scratch_ptr[VEEX_MAX_DEVICES];         // per device: the array's address ON THAT GPU (not the host-side name)
+
+static int scratch_of_current_device(float** out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= VEEX_MAX_DEVICES) { veex_set_error("minmax_static: no current device"); return -3; }
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (g_scratch_ptr[dev] == nullptr) {   // first call on this device (outside stream capture): resolve the symbol once
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || p == nullptr) { veex_set_error("minmax_static: hipGetSymbolAddress failed: %s", hipGetErrorString(e)); return -3; }
+    g_scratch_ptr[dev] = static_cast<float*>(p);
+  }
+  *out = g_scratch_ptr[dev];
+  return 0;
+}
+
+extern "C" {
+
+int veex_minmax_static(const float* x, long long n, float* minmax, hipStream_t st) {
+  if (x == nullptr || minmax == nullptr || n < 1) { veex_set_error("minmax_static: bad arguments"); return -1; }
+  if (n > VEEX_MINMAX_STATIC_MAX_ELEMS) { veex_set_error("minmax_static: %lld elements exceed the limit of %lld per call", n, (long long)VEEX_MINMAX_STATIC_MAX_ELEMS); return -1; }
+  if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) { veex_set_error("minmax_static: x must be 16-byte aligned"); return -1; }
+  const int blocks = veex_minmax_partial_blocks(n);
+  if (blocks > VEEX_MINMAX_STATIC_BLOCKS) { veex_set_error("minmax_static: internal: %d blocks exceed the scratch array", blocks); return -1; }
+  float* part = nullptr;
+  const int rc = scratch_of_current_device(&part);
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL(minmax_partial_kernel, dim3(blocks), dim3(256), 0, st, x, n, part);
+  hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(256), 0, st, part, blocks, minmax);
   VEEX_CHECK_LAUNCH();
   return 0;
 }
