@@ -7,7 +7,7 @@ from vae_eeg_xai_amd import roofline as rl
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-cases = rl.gemm_cases(B)
+cases = rl.gemm_cases(B, bf16=(len(sys.argv) > 3 and sys.argv[3] == "bf16"))
 for label, macs, fn in cases:
     for _ in range(reps):
         fn()

@@ -222,8 +222,132 @@ def dominant_kernel_roofline(net, batch):
     return best
 
 
+def hbm_cases(B=512, L=28):
+    """(label, algorithmic bytes, launch_fn) for every HBM-bound kernel of one train step / attribution pass at
+    batch B, launched stand-alone through the operator-level C-ABI.  Algorithmic bytes = each operand read once +
+    each result written once; reference ops: models.py:10-22 (sample), :156-162 (BCE + KL),
+    :219-223 (conv1), :300-301 (deconv6), train.py:137 (Adam)."""
+    from .net import Net, ADAM_B1, ADAM_B2, ADAM_EPS
+    st = _lib.current_stream
+    keep = []
+    F = 4
+
+    def R(*shape):
+        t = _rand(*shape); keep.append(t); return t
+
+    def E(*shape):
+        t = torch.empty(*shape, device="cuda", dtype=torch.float32); keep.append(t); return t
+
+    cases = []
+    x = torch.rand(B, 40, 40, 1, device="cuda"); keep.append(x)
+    w1, b1 = R(3, 3, 1, 64), R(64)
+    a1 = E(B, 20, 20, 64)
+    cases.append(("conv1_fwd", (x.numel() + a1.numel()) * F,
+                  lambda: check(lib.veex_conv1_fwd(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), a1.data_ptr(), B, st()))))
+    d1 = R(B, 20, 20, 64)
+    nb = lib.veex_conv1_wgrad_blocks(B)
+    slab1 = E(nb, 576)
+    cases.append(("conv1_wgrad", (x.numel() + d1.numel()) * F,
+                  lambda: check(lib.veex_conv1_wgrad(x.data_ptr(), d1.data_ptr(), slab1.data_ptr(), B, st()))))
+    dx = E(B, 40, 40)
+    cases.append(("conv1_dgrad", (d1.numel() + 2 * x.numel()) * F,
+                  lambda: check(lib.veex_conv1_dgrad(d1.data_ptr(), w1.data_ptr(), x.data_ptr(), dx.data_ptr(), B, st()))))
+    a5 = torch.rand(B, 39, 39, 64, device="cuda"); keep.append(a5)
+    sc, sh, w6, b6 = torch.rand(64, device="cuda") + 0.5, R(64), R(2, 2, 1, 64) * 0.1, R(1)
+    keep.extend([sc, sh])
+    dl, rb, ds = E(B, 1600), E(B), E(B)
+    cases.append(("deconv6_bce_fwd", (a5.numel() + x.numel() + dl.numel()) * F,
+                  lambda: check(lib.veex_deconv6_bce_fwd(a5.data_ptr(), sc.data_ptr(), sh.data_ptr(), w6.data_ptr(),
+                                                         b6.data_ptr(), x.data_ptr(), None, None, dl.data_ptr(),
+                                                         rb.data_ptr(), ds.data_ptr(), B, 1.0 / B, st()))))
+    d5, slab6 = E(B, 39, 39, 64), E(B, 448)
+    cases.append(("deconv6_bwd", (a5.numel() + dl.numel() + d5.numel()) * F,
+                  lambda: check(lib.veex_deconv6_bwd(dl.data_ptr(), a5.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                                     w6.data_ptr(), d5.data_ptr(), slab6.data_ptr(), B, st()))))
+    mulv, eps, z, klb = R(B, 2 * L), R(B, L), E(B, L), E(B)
+    cases.append(("reparam_kl_fwd", (mulv.numel() + 2 * eps.numel() + B) * F,
+                  lambda: check(lib.veex_reparam_kl_fwd(mulv.data_ptr(), eps.data_ptr(), z.data_ptr(), klb.data_ptr(), B, L,
+                                                        1, 42, 0, st()))))
+    dz, dmulv = R(B, L), E(B, 2 * L)
+    cases.append(("reparam_kl_bwd", (dz.numel() + mulv.numel() + eps.numel() + dmulv.numel()) * F,
+                  lambda: check(lib.veex_reparam_kl_bwd(dz.data_ptr(), mulv.data_ptr(), eps.data_ptr(), dmulv.data_ptr(), B, L,
+                                                        1.0 / B, st()))))
+    n = 2_288_256
+    p_, g_, m_, v_ = R(n), R(n), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    step, alpha = torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(1, device="cuda")
+    keep.extend([m_, v_, step, alpha])
+    cases.append(("adam_apply (+prepare)", n * 7 * F,
+                  lambda: check(lib.veex_adam(p_.data_ptr(), g_.data_ptr(), m_.data_ptr(), v_.data_ptr(), n, step.data_ptr(),
+                                              alpha.data_ptr(), 1e-5, 1.0, ADAM_B1, ADAM_B2, ADAM_EPS, st()))))
+    # weight-gradient slab reductions as the step launches them (deconv4: 9*64 x 128 gradient)
+    d = WgradDesc(); d.N, d.Hb, d.Wb, d.Cb, d.Hs, d.Ws, d.Cs = B, 19, 19, 64, 17, 17, 128
+    d.kh = d.kw = 3; d.stride, d.pad_begin = 1, 0
+    ns, per = C.c_int32(), C.c_int32()
+    check(lib.veex_wgrad_plan(C.byref(d), C.byref(ns), C.byref(per)), "wgrad_plan")
+    nw = 9 * 64 * 128
+    slab, dW = R(ns.value, nw), E(nw)
+    cases.append((f"slab_sum_vec ({ns.value} slabs, deconv4 dW)", (ns.value + 1) * nw * F,
+                  lambda: check(lib.veex_slab_sum(slab.data_ptr(), ns.value, nw, nw, dW.data_ptr(), None, 1, 0, st()))))
+    dw6 = E(256)
+    cases.append((f"slab_sum_tall ({B} slabs, deconv6 dW)", B * 256 * F,
+                  lambda: check(lib.veex_slab_sum(slab6.data_ptr(), B, 448, 256, dw6.data_ptr(), None, 1, 0, st()))))
+    sw = E(576)
+    cases.append((f"slab_sum_tall ({nb} slabs, conv1 dW)", nb * 576 * F,
+                  lambda: check(lib.veex_slab_sum(slab1.data_ptr(), nb, 576, 576, sw.data_ptr(), None, 1, 0, st()))))
+    g4, a4, e4, o4 = R(B, 4096), torch.rand(B, 4096, device="cuda"), torch.rand(4096, device="cuda") + 0.5, E(B, 4096)
+    chunks = lib.veex_bnrelu_bwd_rows_chunks(B)
+    part = E(chunks, 3, 4096)
+    keep.extend([a4, e4])
+    cases.append(("bnrelu_bwd_rows (dec.dense)", (3 * B * 4096 + chunks * 3 * 4096) * F,
+                  lambda: check(lib.veex_bnrelu_bwd_rows(g4.data_ptr(), a4.data_ptr(), e4.data_ptr(), o4.data_ptr(),
+                                                         part.data_ptr(), B, 4096, 4096, st()))))
+    mean, rstd, db, dg, dbt = R(4096), torch.rand(4096, device="cuda") + 0.5, E(4096), E(4096), E(4096)
+    keep.append(rstd)
+    cases.append(("colsum_finalize (dec.dense)", (chunks * 3 * 4096 + 6 * 4096) * F,
+                  lambda: check(lib.veex_colsum_finalize(part.data_ptr(), chunks, 3 * 4096, 4096, 4096, e4.data_ptr(),
+                                                         mean.data_ptr(), rstd.data_ptr(), db.data_ptr(), dg.data_ptr(),
+                                                         dbt.data_ptr(), st()))))
+    nbn = 5184
+    ga, be, mu, va, s1, s2, s3 = R(nbn), R(nbn), R(nbn), torch.rand(nbn, device="cuda") + 0.5, E(nbn), E(nbn), E(nbn)
+    keep.append(va)
+    cases.append(("bn_prepare", 7 * nbn * F,
+                  lambda: check(lib.veex_bn_prepare(ga.data_ptr(), be.data_ptr(), mu.data_ptr(), va.data_ptr(), s1.data_ptr(),
+                                                    s2.data_ptr(), s3.data_ptr(), nbn, 1e-3, st()))))
+    # either side of the path: normalize / denormalize over the 100k-map set
+    big = torch.rand(100_000 * 1600, device="cuda"); keep.append(big)
+    out_big = E(big.numel())
+    mm = E(2)
+    pb = E(2 * lib.veex_minmax_partial_blocks(big.numel()))
+    cases.append(("minmax (100k maps)", big.numel() * F,
+                  lambda: check(lib.veex_minmax(big.data_ptr(), big.numel(), pb.data_ptr(), mm.data_ptr(), st()))))
+    cases.append(("normalize (100k maps)", 2 * big.numel() * F,
+                  lambda: check(lib.veex_normalize(big.data_ptr(), mm.data_ptr(), out_big.data_ptr(), big.numel(), st()))))
+    cases.append(("denormalize (100k maps)", 2 * big.numel() * F,
+                  lambda: check(lib.veex_denormalize(big.data_ptr(), mm.data_ptr(), out_big.data_ptr(), big.numel(), st()))))
+    hbm_cases._keep = keep
+    return cases
+
+
+def hbm_table(B=512):
+    """Achieved HBM GB/s of every fused elementwise / reduction kernel against the 8 TB/s peak (north_star)."""
+    rows = []
+    for label, nbytes, fn in hbm_cases(B):
+        t = _time_launch(fn, iters=20, warm=3)
+        rows.append({"kernel": label, "bytes": nbytes, "us": t * 1e6, "gbs": nbytes / t / 1e9, "frac": nbytes / t / 1e9 / PEAK_HBM_GBS})
+    return rows
+
+
 if __name__ == "__main__":
     import sys
+    if "--hbm" in sys.argv:
+        args = [a for a in sys.argv[1:] if a != "--hbm"]
+        B = int(args[0]) if args else 512
+        print(f"HBM-bound kernels at batch {B}: algorithmic bytes (operands once + results once), HIP-event time per launch on the "
+              f"launch stream (median of 3 groups of 20 back-to-back launches), against {PEAK_HBM_GBS:.0f} GB/s.\n"
+              "Launches under ~10 us are bounded by the 4.6 us begin-to-end floor of any kernel here, not by bytes.")
+        for r in hbm_table(B):
+            print(f"{r['kernel']:40s} {r['bytes'] / 1e6:9.2f} MB {r['us']:8.1f} us {r['gbs']:8.0f} GB/s  {100 * r['frac']:5.1f}% of HBM peak")
+        sys.exit(0)
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     bf = len(sys.argv) > 2 and sys.argv[2] == "bf16"
     tot = 0.0
