@@ -92,3 +92,27 @@ def test_bf16_training_reduces_the_loss():
         first = loss if first is None else first
         last = loss
     assert np.isfinite(last) and last < first
+
+
+def test_lean_bf16_gather_kernel_is_bit_identical_to_the_general_one():
+    """VEEX_BFV3=1 routes every bf16 gather launch with a bf16 A copy through gather_gemm_bf16_v3.hip (same tiles,
+    same K order inside a tile -> the same bits); it is off by default because it measures the same."""
+    import torch
+    from vae_eeg_xai_amd import _lib
+    from vae_eeg_xai_amd.net import Net
+    L, B = 28, 200
+    p = vo.init_params(L, "vae", seed=3, jitter=0.1)
+    x = vo.synth_topomaps(B, 5)
+    eps = np.random.default_rng(7).standard_normal((B, L)).astype(np.float32)
+    res = []
+    try:
+        for flag in ("0", "1"):
+            _lib.setenv("VEEX_BFV3", flag)
+            net = Net(L, "vae", compute="bf16")
+            net.set_weights_dict(p)
+            net.train_fwd_bwd(x, eps)
+            torch.cuda.synchronize()
+            res.append(net.grads.clone())
+    finally:
+        _lib.setenv("VEEX_BFV3", "0")
+    assert torch.equal(res[0], res[1])

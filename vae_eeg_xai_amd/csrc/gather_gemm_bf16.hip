@@ -381,6 +381,10 @@ int veex_launch_gather_gemm_bf16(GGParams& p, int mtiles, hipStream_t st) {
   if ((long long)p.Nb * p.Hout * p.Wout >= (1LL << 24)) { veex_set_error("gather_gemm(bf16): more than 2^24 output pixels"); return -1; }
   if ((long long)p.Nb * p.Hout * p.Wout * p.Cout * 4 >= 0x7FFF0000LL) { veex_set_error("gather_gemm(bf16): output of 2 GiB or more"); return -1; }
   const int bm = veex_gg_bm(p);
+  // The lean kernel (gather_gemm_bf16_v3.hip) can take every launch whose A operand is a bf16 consumer copy.  Off by
+  // default: it issues 3-8x fewer instructions per MFMA and keeps up to 4 chunks of loads in flight, and measures
+  // the same (+-3 %) -- these launches are bound by what a CU can gather from L2, not by issue.
+  if (veex_env_int("VEEX_BFV3", 0) && veex_gg_bf16_v3_ok(p)) return veex_launch_gather_gemm_bf16_v3(p, mtiles, bm, st);
   const int bn = (bm == 128 && p.Cout > 64) ? 128 : 64;
   const int ntiles = (p.Cout + bn - 1) / bn;
   if (p.nsplit > 1) {

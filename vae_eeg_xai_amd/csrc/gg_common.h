@@ -237,6 +237,8 @@ __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off)
 
 // launch-side helpers shared by the fp32 and bf16 engines
 int veex_launch_gather_gemm_bf16(GGParams& p, int mtiles, hipStream_t st);   // gather_gemm_bf16.hip
+int veex_gg_bf16_v3_ok(const GGParams& p);                                     // gather_gemm_bf16_v3.hip
+int veex_launch_gather_gemm_bf16_v3(GGParams& p, int mtiles, int bm, hipStream_t st);
 int veex_gg_v3_ok(const GGParams& p);                                          // gather_gemm_v3.hip
 int veex_launch_gather_gemm_v3(GGParams& p, int mtiles, hipStream_t st);
 

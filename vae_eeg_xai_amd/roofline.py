@@ -173,13 +173,39 @@ def gemm_cases(B, bf16=False):
     return cases
 
 
+def algorithmic_bytes(label, B, bf16=False):
+    """HBM bytes one launch of gemm_cases() must move: every operand read once, every result written once, in the
+    element types the engine uses (fp32 engine: everything fp32; bf16 engine: operands are bf16 consumer copies,
+    results are written as fp32 AND as the bf16 copy the next GEMM reads; a backward epilogue also reads the fp32
+    activation; a weight gradient writes the fp32 gradient once -- split-K slabs are overhead, not algorithm)."""
+    layer, kind = label.rsplit(".", 1)
+    for name, cin, cout, k, s, pb, hin, hout, macs in CONVS + DECONVS:
+        if name == layer:
+            break
+    else:
+        raise KeyError(label)
+    n_in, n_out, n_w = B * hin * hin * cin, B * hout * hout * cout, k * k * cin * cout
+    e = 2 if bf16 else 4                      # operand element size
+    ocopy = 2 if bf16 else 0                  # extra bf16 copy of a result
+    if kind == "fwd":
+        return n_in * e + n_w * e + n_out * (4 + ocopy)
+    if kind == "dgrad":                       # reads d(out) and the activation of the layer below, writes d(in)
+        aux = 0 if (layer == "dec.deconv1") else n_in * 4
+        return n_out * e + n_w * e + aux + n_in * (4 + ocopy)
+    return n_in * e + n_out * e + n_w * 4     # wgrad
+
+
 def layer_table(B=512, iters=10, bf16=False):
     rows = []
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     for label, macs, fn in gemm_cases(B, bf16):
         t = _time_launch(fn, iters)
         tf = 2.0 * macs / t / 1e12
-        rows.append({"kernel": label, "us": t * 1e6, "tflops": tf, "frac": tf / peak})
+        nbytes = algorithmic_bytes(label, B, bf16)
+        t_roof = max(2.0 * macs / (peak * 1e12), nbytes / (PEAK_HBM_GBS * 1e9))
+        rows.append({"kernel": label, "us": t * 1e6, "tflops": tf, "frac": tf / peak, "bytes": nbytes,
+                     "roof_us": t_roof * 1e6, "roof": "mfma" if 2.0 * macs / (peak * 1e12) >= nbytes / (PEAK_HBM_GBS * 1e9) else "hbm",
+                     "frac_roof": t_roof / t})
     return rows
 
 
@@ -351,7 +377,10 @@ if __name__ == "__main__":
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     bf = len(sys.argv) > 2 and sys.argv[2] == "bf16"
     tot = 0.0
+    print(f"MFMA launches of one train step at batch {B} ({'bf16' if bf else 'fp32'} engine), HIP-event time per launch; roof = "
+          f"max(FLOP / {'2500' if bf else '157.3'} TFLOP/s, algorithmic bytes / 8 TB/s)")
     for r in layer_table(B, bf16=bf):
         tot += r["us"]
-        print(f"{r['kernel']:22s} {r['us']:8.1f} us  {r['tflops']:6.1f} TF  {100 * r['frac']:5.1f}% of {'bf16' if bf else 'f32'} MFMA peak")
+        print(f"{r['kernel']:22s} {r['us']:8.1f} us  {r['tflops']:6.1f} TF  {100 * r['frac']:5.1f}% of {'bf16' if bf else 'f32'} MFMA peak"
+              f"  bytes {r['bytes'] / 1e6:7.1f} MB  roof {r['roof_us']:6.1f} us ({r['roof']})  {100 * r['frac_roof']:5.1f}% of roof")
     print(f"sum {tot:.1f} us")
