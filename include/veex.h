@@ -83,6 +83,8 @@ typedef struct VeexGemmDesc {
   int32_t reserved_;
   const void* weight_bf16; /* optional packed bf16 weights [tap][Cout][Cin] (veex_pack_weights_bf16): selects the
                               bf16-MFMA kernel (fp32 accumulate) when Cin % 32 == 0 and N*Hout*Wout >= 4096 */
+  const float* weight_t;   /* optional, mode 0, fp32 engine: the same weights as [tap][Cout][Cin] (veex_transpose_weights_f32);
+                              same result bit for bit, the kernel's weight fragment then is one 16-byte LDS read */
 } VeexGemmDesc;
 int veex_gather_gemm(const VeexGemmDesc* d, veexStream_t stream);
 /* bf16 copy of one layer's kernel for veex_gather_gemm: src fp32 [taps][rows][cols] ->
@@ -90,6 +92,8 @@ int veex_gather_gemm(const VeexGemmDesc* d, veexStream_t stream);
  * (kh,kw,Cin,Cout) need transpose=1 for the forward (mode 0) and 0 for the input gradient (mode 1);
  * Conv2DTranspose kernels (kh,kw,Cout,Cin) the other way round. */
 int veex_pack_weights_bf16(const float* src, void* dst, int taps, int rows, int cols, int transpose, veexStream_t s);
+/* fp32 transposed copy of one layer's kernel: dst[tap][c][r] = src[tap][r][c] (VeexGemmDesc::weight_t) */
+int veex_transpose_weights_f32(const float* src, float* dst, int taps, int rows, int cols, veexStream_t s);
 /* rows of the partials slab an epilogue-1 launch of this descriptor writes */
 int veex_gather_gemm_m_tiles(const VeexGemmDesc* d);
 

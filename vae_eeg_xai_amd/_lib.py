@@ -33,7 +33,7 @@ class GemmDesc(C.Structure):
         ("epilogue", C.c_int32), ("relu", C.c_int32), ("e_channels", C.c_int32), ("nsplit", C.c_int32),
         ("in_bf16", C.c_void_p), ("out_bf16", C.c_void_p), ("out_scale", C.c_void_p), ("out_shift", C.c_void_p),
         ("out_channels", C.c_int32), ("reserved_", C.c_int32),
-        ("weight_bf16", C.c_void_p),
+        ("weight_bf16", C.c_void_p), ("weight_t", C.c_void_p),
     ]
 
 
@@ -62,6 +62,7 @@ SIGNATURES = {
     "veex_gather_gemm": (_I, [C.POINTER(GemmDesc), _P]),
     "veex_gather_gemm_m_tiles": (_I, [C.POINTER(GemmDesc)]),
     "veex_pack_weights_bf16": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "veex_transpose_weights_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "veex_net_set_compute": (_I, [_P, _I]),
     "veex_net_set_side_stream": (_I, [_P, _P]),
     "veex_net_set_batch_divisor": (_I, [_P, _D]),

@@ -549,11 +549,13 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
 // barriers and epilogues; the f32 MFMA is slow enough that operand re-use is not the limit); the bf16
 // engine keeps 128-row tiles for forward launches (operand re-use matters at 16x the MFMA rate) and
 // takes 64x64 for the heavier BatchNorm/ReLU-backward epilogue and for launches of < 256 blocks.
+static bool gg_fast_ok_fwd(const GGParams& p);
 int veex_gg_bm(const GGParams& p) {
   const long long M = (long long)p.Nb * p.Hout * p.Wout;
   if (M < 4096) return 64;
   const int force = veex_env_int("VEEX_BM", 0);
   if (force == 64 || force == 128) return force;
+  if (p.Wbf == nullptr && veex_env_int("VEEX_GGV3", 1) && gg_fast_ok_fwd(p) && veex_gg_v3_ok(p)) return veex_gg_v3_bm(p);   // lean fp32 kernel
   if (p.Wbf == nullptr || p.Cin % 32 != 0) return 64;
   const long long blocks = ((M + 127) / 128) * ((p.Cout > 64) ? (p.Cout + 127) / 128 : 1);
   // BatchNorm/ReLU-backward epilogue: 64-row tiles, except the stride-1 multi-tap input gradients (deconv2, deconv4:
@@ -675,6 +677,8 @@ static int gg_launch_cfg(GGParams& p, int mtiles, bool fast, hipStream_t st) {
   return 0;
 }
 
+static bool gg_fast_ok(const GGParams& p);
+static bool gg_fast_ok_fwd(const GGParams& p) { return gg_fast_ok(p); }
 // fast path: 16-byte buffer loads everywhere, 32-bit byte offsets, tap-validity bit mask
 static bool gg_fast_ok(const GGParams& p) {
   const long long Mtot = (long long)p.Nb * p.Hout * p.Wout;
@@ -725,7 +729,7 @@ int veex_launch_gather_gemm(const GGParams& pin, hipStream_t st) {
   const bool fast = gg_fast_ok(p);
   if (gg_bf16_dispatch(p, fast)) return veex_launch_gather_gemm_bf16(p, mtiles, st);
   if (p.Out == nullptr) { veex_set_error("gather_gemm: null output (only the bf16 engine can write the bf16 copy alone)"); return -1; }
-  if (bm == 64 && fast && veex_env_int("VEEX_GGV3", 1) && veex_gg_v3_ok(p)) return veex_launch_gather_gemm_v3(p, mtiles, st);
+  if (fast && veex_env_int("VEEX_GGV3", 1) && veex_gg_v3_ok(p) && bm == veex_gg_v3_bm(p)) return veex_launch_gather_gemm_v3(p, mtiles, st);
   if (bm == 128 && bn == 128 && fast) return gg_launch_cfg<128, 128>(p, mtiles, true, st);
   if (bm == 128 && bn == 64 && fast) return gg_launch_cfg<128, 64>(p, mtiles, true, st);
   if (bm == 64 && fast) return gg_launch_cfg<64, 64>(p, mtiles, true, st);

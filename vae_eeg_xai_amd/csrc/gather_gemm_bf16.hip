@@ -325,6 +325,59 @@ int veex_pack_weights_bf16_multi(int n, const float* const* src, void* const* ds
   return 0;
 }
 
+// fp32 transposed copies for the lean fp32 kernel's mode-0 launches (GGParams::Wt): dst[t][c][r] = src[t][r][c]
+struct TrJob { const float* src; float* dst; int taps, R, C, block0, blocks; };
+struct TrJobs { int n; TrJob j[16]; };
+__global__ __launch_bounds__(256) void transpose_weights_f32_multi_kernel(const TrJobs jobs) {
+  __shared__ float tile[32][33];
+  int k = 0;
+  while (k + 1 < jobs.n && (int)blockIdx.x >= jobs.j[k + 1].block0) ++k;
+  const TrJob J = jobs.j[k];
+  // one 32x32 tile of one tap per block step: coalesced 128-byte reads along C and writes along R
+  const int tr = (J.R + 31) / 32, tc = (J.C + 31) / 32, per_tap = tr * tc, total = J.taps * per_tap;
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;   // 32 x 8
+  for (int t = blockIdx.x - J.block0; t < total; t += J.blocks) {
+    const int tap = t / per_tap, rem = t - tap * per_tap, br = rem / tc, bc = rem - br * tc;
+    const float* s = J.src + (long long)tap * J.R * J.C;
+    float* d = J.dst + (long long)tap * J.R * J.C;
+#pragma unroll
+    for (int y = ly; y < 32; y += 8) {
+      const int r = br * 32 + y, c = bc * 32 + lx;
+      tile[y][lx] = (r < J.R && c < J.C) ? s[(long long)r * J.C + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int y = ly; y < 32; y += 8) {
+      const int c = bc * 32 + y, r = br * 32 + lx;
+      if (r < J.R && c < J.C) d[(long long)c * J.R + r] = tile[lx][y];
+    }
+    __syncthreads();
+  }
+}
+int veex_transpose_weights_f32_multi(int n, const float* const* src, float* const* dst, const int* taps, const int* rows,
+                                     const int* cols, hipStream_t st) {
+  if (n < 1 || n > 16) { veex_set_error("transpose_weights_f32_multi: 1..16 jobs"); return -1; }
+  TrJobs jobs; jobs.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    const int tiles = taps[i] * ((rows[i] + 31) / 32) * ((cols[i] + 31) / 32);
+    int b = (tiles + 1) / 2;
+    if (b < 1) b = 1;
+    if (b > 144) b = 144;
+    jobs.j[i].src = src[i]; jobs.j[i].dst = dst[i]; jobs.j[i].taps = taps[i]; jobs.j[i].R = rows[i]; jobs.j[i].C = cols[i];
+    jobs.j[i].block0 = total; jobs.j[i].blocks = b;
+    total += b;
+  }
+  hipLaunchKernelGGL(transpose_weights_f32_multi_kernel, dim3(total), dim3(256), 0, st, jobs);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int veex_transpose_weights_f32(const float* src, float* dst, int taps, int rows, int cols, hipStream_t st) {
+  if (src == nullptr || dst == nullptr || taps < 1 || rows < 1 || cols < 1) { veex_set_error("transpose_weights_f32: bad arguments"); return -1; }
+  return veex_transpose_weights_f32_multi(1, &src, &dst, &taps, &rows, &cols, st);
+}
+
 extern "C" int veex_pack_weights_bf16(const float* src, void* dst, int taps, int rows, int cols, int transpose,
                                       hipStream_t st) {
   if (src == nullptr || dst == nullptr || taps < 1 || rows < 1 || cols < 1) { veex_set_error("pack_weights_bf16: bad arguments"); return -1; }

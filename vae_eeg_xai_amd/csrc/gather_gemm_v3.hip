@@ -37,13 +37,21 @@ __device__ __forceinline__ void g3_divmod(int r, int d, float inv, int& qo, int&
   qo = q; rem = m;
 }
 
-template <bool MODE1, int AFF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void gather_gemm_v3_kernel(const GGParams p) {
-  constexpr int BM = 64, BN = 64, BK = 16;
+// BPK (mode 0 only): the weights come as the packed copy GGParams::Wt = [tap][Cout][Cin] (K contiguous, the layout mode 1
+// has natively), so the B tile is staged and read exactly as in mode 1; same values in the same k order: same bits.
+// NWM x NWN waves of one 32x32 accumulator each: tile 32*NWM rows x 32*NWN columns, 64*NWM*NWN threads.  2 x 2 is the
+// 64x64 tile; 4 x 2 / 2 x 4 / 4 x 4 move 25 / 25 / 50 % fewer operand bytes from L2 per MFMA at the same registers per
+// wave (ablation, profiles/r02_f32_lean_ablation_*.txt: with the MFMAs removed a 64x64 launch still takes half its
+// time, almost all of it in the operand loads -- 1.7 GB from L2 for deconv4 forward).
+template <bool MODE1, int AFF, bool BPK = false, int NWM = 2, int NWN = 2>
+__global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(7, 8))) void gather_gemm_v3_kernel(const GGParams p) {
+  constexpr int BM = 32 * NWM, BN = 32 * NWN, BK = 16;
+  static_assert((NWM == 2 && NWN == 2) || MODE1 || BPK, "wide tiles stage B as [n][k] rows");
   constexpr int LDK = BK + 4;
   constexpr int A_ELEMS = BM * LDK;
   constexpr int LDN = BN + 4;
-  constexpr int B_ELEMS = MODE1 ? BN * LDK : BK * LDN;
+  constexpr bool BROW = MODE1 || BPK;      // B tile as [n][k] rows
+  constexpr int B_ELEMS = BROW ? BN * LDK : BK * LDN;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
@@ -53,8 +61,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
   const int lh = lane >> 5, l31 = lane & 31;
+  // staging roles, uniform per wave: thread t stages 16-byte piece t % 4 of A row t / 4 (t < 4*BM) and of B row t / 4 (t < 4*BN)
+  const int swave = __builtin_amdgcn_readfirstlane(wave);
+  constexpr int NWAVES = NWM * NWN;
+  const bool hasA = (BM / 16 >= NWAVES) || swave < BM / 16, hasB = (BN / 16 >= NWAVES) || swave < BN / 16;
 
   int bnt, btile, kz;
   if (p.remap == 2) {
@@ -118,7 +130,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(reinterpret_cast<const char*>(p.A)) - bias_bytes, 0, (int)(a_total + (unsigned)bias_bytes), 0x00020000);
   const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.W), 0, (int)((unsigned)p.kh * p.kw * p.Cin * p.Cout * 4u), 0x00020000);
+      const_cast<float*>(BPK ? p.Wt : p.W), 0, (int)((unsigned)p.kh * p.kw * p.Cin * p.Cout * 4u), 0x00020000);
   const unsigned aff_bytes = (AFF != 0) ? (unsigned)(p.aff_mask + 1) * 4u : 0u;
   const int aff_bias = (AFF == 2) ? bias_bytes : 0;
   const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(
@@ -132,7 +144,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   {
     const int m = m0 + lr;
     unsigned out_off = 0x80000000u;   // + any column offset stays out of range: the store is dropped
-    if (m < Mph) {
+    if (m < Mph && hasA) {
       int n, j, ii;
       row_nji(m, n, j, ii);
       const int oy = ostep * j + oy0, ox = ostep * ii + ox0;
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
       }
       a_inv = ~mk;   // bits >= ntaps (bit 31 included: "chunk past the end") stay set
     }
-    if (q == 0) s_offb[lr] = out_off;   // the epilogue's output row byte offsets (read after the K loop's barriers)
+    if (q == 0 && hasA) s_offb[lr] = out_off;   // the epilogue's output row byte offsets (read after the K loop's barriers)
   }
   // valid-tap set of the tile: split-K launches keep every tap (their chunk ranges are planned on the host)
   __syncthreads();
@@ -172,9 +184,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   const int nvalid = __builtin_popcount(tile_mk);
   // ---- B loader ----
   unsigned b_voff;
-  if (MODE1) {   // [tap][Cout][Cin]: row n0 + tid/4, quad q along Cin
+  if (BROW) {    // [tap][Cout][Cin]: row n0 + tid/4, quad q along Cin
     const int n = n0 + lr;
-    b_voff = (n < p.Cout) ? (unsigned)((n * p.Cin + 4 * q) * 4) : VEEX_OOB;
+    b_voff = (n < p.Cout && hasB) ? (unsigned)((n * p.Cin + 4 * q) * 4) : VEEX_OOB;
   } else {       // [tap][Cin][Cout]: row tid/16, quad tid%16 along Cout
     const int n = n0 + 4 * (tid & 15);
     b_voff = (n < p.Cout) ? (unsigned)(((tid >> 4) * p.Cout + n) * 4) : VEEX_OOB;
@@ -186,7 +198,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 
   const int nchunks = nvalid * cpt;
   const int c_begin = kz * p.chunks_per_split;
+#ifdef VEEX_DEBUG_TIMING   // timing experiments (results wrong): 1 = no K loop, 2 = no epilogue, 4 = no MFMA, 8 = no LDS stores, 16 = no loads
+  const int c_end = (p.tap_inner & 1) ? c_begin : min(nchunks, c_begin + p.chunks_per_split);
+#else
   const int c_end = min(nchunks, c_begin + p.chunks_per_split);
+#endif
   // running (tap, channel slice) of the next chunk to load; chunks are loaded strictly in order: per channel slice
   // the set bits of tile_mk in ascending order
   int it_c = c_begin;
@@ -208,28 +224,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     if (it_bits == 0u) { it_bits = tile_mk; ++it_cc; }
 
     const unsigned m = (unsigned)__builtin_amdgcn_sbfe(a_inv, tapi, 1);   // 0 or 0xFFFFFFFF
+    // every thread issues every load: a thread without the role has its offset out of range (zeros, no memory
+    // access).  Branching around the loads made the compiler wait for ALL outstanding loads at the joins.
     st.ra = bload4s(rA, a_voff | m, delta);
     if (AFF == 1) {
-      st.rsc = bload4s(rS, s_voff, ci0b);
+      st.rsc = bload4s(rS, s_voff | m, ci0b);
       st.rsh = bload4s(rH, s_voff | m, ci0b);
     } else if (AFF == 2) {
       st.rsc = bload4s(rS, a_voff2 | m, delta);
       st.rsh = bload4s(rH, a_voff2 | m, delta);
     }
-    st.rb = bload4s(rW, b_voff, tap * tap_bytes + (MODE1 ? ci0b : ci0b * p.Cout));
+    st.rb = bload4s(rW, b_voff, tap * tap_bytes + (BROW ? ci0b : ci0b * p.Cout));
   };
 
   auto store_chunk = [&](const Stage& st, int buf) {
     float* as = As + buf * A_ELEMS;
     float* bs = Bs + buf * B_ELEMS;
-    float4 v = st.ra;
-    if (AFF != 0) {   // padding pixels: value 0, shift 0 -> stay exactly 0
-      v.x = fmaf(v.x, st.rsc.x, st.rsh.x); v.y = fmaf(v.y, st.rsc.y, st.rsh.y);
-      v.z = fmaf(v.z, st.rsc.z, st.rsh.z); v.w = fmaf(v.w, st.rsc.w, st.rsh.w);
+    if (hasA) {
+      float4 v = st.ra;
+      if (AFF != 0) {   // padding pixels: value 0, shift 0 -> stay exactly 0
+        v.x = fmaf(v.x, st.rsc.x, st.rsh.x); v.y = fmaf(v.y, st.rsc.y, st.rsh.y);
+        v.z = fmaf(v.z, st.rsc.z, st.rsh.z); v.w = fmaf(v.w, st.rsc.w, st.rsh.w);
+      }
+      *reinterpret_cast<float4*>(as + lr * LDK + 4 * q) = v;
     }
-    *reinterpret_cast<float4*>(as + lr * LDK + 4 * q) = v;
-    if (MODE1) *reinterpret_cast<float4*>(bs + lr * LDK + 4 * q) = st.rb;
-    else       *reinterpret_cast<float4*>(bs + (tid >> 4) * LDN + 4 * (tid & 15)) = st.rb;
+    if (hasB) {
+      if (BROW) *reinterpret_cast<float4*>(bs + lr * LDK + 4 * q) = st.rb;
+      else      *reinterpret_cast<float4*>(bs + (tid >> 4) * LDN + 4 * (tid & 15)) = st.rb;
+    }
   };
 
   f32x16 acc;
@@ -239,14 +261,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   // K order inside a chunk is permuted: lanes 0-31 feed k = 0..7, lanes 32-63 k = 8..15
   auto compute = [&](int cur) {
     const float* as = As + cur * A_ELEMS + (wm * 32 + l31) * LDK + 8 * lh;
-    const float* bs = MODE1 ? (Bs + cur * B_ELEMS + (wn * 32 + l31) * LDK + 8 * lh)
-                            : (Bs + cur * B_ELEMS + (8 * lh) * LDN + wn * 32 + l31);
+    const float* bs = BROW ? (Bs + cur * B_ELEMS + (wn * 32 + l31) * LDK + 8 * lh)
+                           : (Bs + cur * B_ELEMS + (8 * lh) * LDN + wn * 32 + l31);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       float av[4], bv[4];
       const float4 t = *reinterpret_cast<const float4*>(as + 4 * half);
       av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
-      if (MODE1) {
+      if (BROW) {
         const float4 u = *reinterpret_cast<const float4*>(bs + 4 * half);
         bv[0] = u.x; bv[1] = u.y; bv[2] = u.z; bv[3] = u.w;
       } else {
@@ -264,6 +286,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   store_chunk(s0, 0);
   load_chunk(s0);
   __syncthreads();
+#ifdef VEEX_DEBUG_TIMING
+  for (int c = c_begin; c < c_end; c += 2) {
+    if (!(p.tap_inner & 16)) load_chunk(s1);
+    if (!(p.tap_inner & 4)) compute(0);
+    if (!(p.tap_inner & 8)) store_chunk(s0, 1); else if (s0.ra.x == 12345.f) acc[0] += 1.f;
+    __syncthreads();
+    if (!(p.tap_inner & 16)) load_chunk(s0);
+    if (!(p.tap_inner & 4)) compute(1);
+    if (!(p.tap_inner & 8)) store_chunk(s1, 0); else if (s1.ra.x == 12345.f) acc[0] += 1.f;
+    __syncthreads();
+  }
+  if (p.tap_inner & 2) { if (acc[0] == 12345.f) p.Out[0] = 1.f; return; }
+#else
   for (int c = c_begin; c < c_end; c += 2) {
     load_chunk(s1);
     compute(0);
@@ -274,6 +309,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     store_chunk(s1, 0);
     __syncthreads();
   }
+#endif
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
   const int col = n0 + wn * 32 + l31;
@@ -338,7 +374,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 
   if (p.epi == VEEX_EPI_BWD && p.partials != nullptr) {
     // column sums: lane halves -> the two waves sharing the columns -> one row of the partial slab
-    float* s_red = As;   // [2][BN][3]; safe: every wave passed the loop's last barrier
+    float* s_red = As;   // [NWM][BN][3]; safe: every wave passed the loop's last barrier
     cs1 += __shfl_xor(cs1, 32);
     cs2 += __shfl_xor(cs2, 32);
     cs3 += __shfl_xor(cs3, 32);
@@ -350,9 +386,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
     }
     __syncthreads();
     if (tid < BN && n0 + tid < p.Cout) {
-      const float t1 = s_red[tid * 3 + 0] + s_red[(BN + tid) * 3 + 0];
-      const float t2 = s_red[tid * 3 + 1] + s_red[(BN + tid) * 3 + 1];
-      const float t3 = s_red[tid * 3 + 2] + s_red[(BN + tid) * 3 + 2];
+      float t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWM; ++w) {     // in wave order: 2 x 2 sums exactly as before
+        t1 += s_red[(w * BN + tid) * 3 + 0];
+        t2 += s_red[(w * BN + tid) * 3 + 1];
+        t3 += s_red[(w * BN + tid) * 3 + 2];
+      }
       float* pp = p.partials + (long long)btile * 3 * p.Cout + n0 + tid;
       pp[0] = t1;
       pp[p.Cout] = t2;
@@ -361,12 +401,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
   }
 }
 
-template <bool MODE1>
+template <bool MODE1, bool BPK, int NWM, int NWN>
 static void gg3_launch(const GGParams& p, int aff, dim3 grid, hipStream_t st) {
-  constexpr size_t lds = (2 * 64 * 20 + 2 * (MODE1 ? 64 * 20 : 16 * 68)) * sizeof(float) + (64 + 4) * sizeof(unsigned);
-  if (aff == 0) hipLaunchKernelGGL((gather_gemm_v3_kernel<MODE1, 0>), grid, dim3(256), lds, st, p);
-  else if (aff == 1) hipLaunchKernelGGL((gather_gemm_v3_kernel<MODE1, 1>), grid, dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((gather_gemm_v3_kernel<MODE1, 2>), grid, dim3(256), lds, st, p);
+  constexpr int BM = 32 * NWM, BN = 32 * NWN;
+  constexpr size_t lds = (2 * BM * 20 + 2 * ((MODE1 || BPK) ? BN * 20 : 16 * 68)) * sizeof(float) + (BM + 4) * sizeof(unsigned);
+  const dim3 blk(64 * NWM * NWN);
+  if (aff == 0) hipLaunchKernelGGL((gather_gemm_v3_kernel<MODE1, 0, BPK, NWM, NWN>), grid, blk, lds, st, p);
+  else if (aff == 1) hipLaunchKernelGGL((gather_gemm_v3_kernel<MODE1, 1, BPK, NWM, NWN>), grid, blk, lds, st, p);
+  else hipLaunchKernelGGL((gather_gemm_v3_kernel<MODE1, 2, BPK, NWM, NWN>), grid, blk, lds, st, p);
 }
 
 // 1: the lean kernel can run this launch (64-row tiles already chosen by the caller)
@@ -386,9 +428,24 @@ int veex_gg_v3_ok(const GGParams& p) {
   return 1;
 }
 
-// p: validated by veex_launch_gather_gemm, phase tables filled for 64-row tiles
+// Tile of the lean kernel for this launch: rows (64 or 128; veex_gg_bm is the one source: callers size the column
+// partials by it) x columns.  Wide tiles need the [n][k] weight layout: mode 1, or mode 0 with the packed copy.
+int veex_gg_v3_bm(const GGParams& p) {
+  const long long M = (long long)p.Nb * p.Hout * p.Wout;
+  if (veex_env_int("VEEX_F32BM", 64) != 128 || M < 8192 || p.nsplit > 1) return 64;
+  if (!(p.mode == 1 || (p.Wt != nullptr && veex_env_int("VEEX_WPACKF", 1)))) return 64;
+  return 128;
+}
+static int gg_v3_bn(const GGParams& p) {
+  if (veex_env_int("VEEX_F32BN", 64) != 128 || p.Cout < 128 || p.nsplit > 1) return 64;
+  if (!(p.mode == 1 || (p.Wt != nullptr && veex_env_int("VEEX_WPACKF", 1)))) return 64;
+  return 128;
+}
+
+// p: validated by veex_launch_gather_gemm, phase tables filled for veex_gg_bm(p)-row tiles
 int veex_launch_gather_gemm_v3(GGParams& p, int mtiles, hipStream_t st) {
-  const int ntiles = (p.Cout + 63) / 64;
+  const int bm = veex_gg_v3_bm(p), bn = gg_v3_bn(p);
+  const int ntiles = (p.Cout + bn - 1) / bn;
   if (p.nsplit > 1) {
     const int nchunks = p.kh * p.kw * (p.Cin / 16);
     p.chunks_per_split = (nchunks + p.nsplit - 1) / p.nsplit;
@@ -406,13 +463,26 @@ int veex_launch_gather_gemm_v3(GGParams& p, int mtiles, hipStream_t st) {
     // tiles line up with the image rows, plain round-robin otherwise
     const long long rowlen = (long long)p.Nb * p.Wout;
     p.remap = 0;
-    if (p.nphase == 1 && rowlen % 64 == 0 && (rowlen / 64) % 8 == 0 && (long long)mtiles == p.Hout * (rowlen / 64)) {
-      p.remap = 2; p.row_tiles = (int)(rowlen / 64);
+    if (p.nphase == 1 && rowlen % bm == 0 && (rowlen / bm) % 8 == 0 && (long long)mtiles == p.Hout * (rowlen / bm)) {
+      p.remap = 2; p.row_tiles = (int)(rowlen / bm);
     }
   }
   const int aff = (p.a_scale == nullptr) ? 0 : (p.aff_spatial ? 2 : 1);
-  if (p.mode == 1) gg3_launch<true>(p, aff, grid, st);
-  else gg3_launch<false>(p, aff, grid, st);
+#ifdef VEEX_DEBUG_TIMING
+  p.tap_inner = veex_env_int("VEEX_F32DBG", 0);
+#endif
+  const bool bpk = p.mode == 0 && p.Wt != nullptr && veex_env_int("VEEX_WPACKF", 1);
+  if (bm == 64 && bn == 64) {
+    if (p.mode == 1) gg3_launch<true, false, 2, 2>(p, aff, grid, st);
+    else if (bpk) gg3_launch<false, true, 2, 2>(p, aff, grid, st);
+    else gg3_launch<false, false, 2, 2>(p, aff, grid, st);
+  } else if (bm == 128 && bn == 64) {
+    if (p.mode == 1) gg3_launch<true, false, 4, 2>(p, aff, grid, st); else gg3_launch<false, true, 4, 2>(p, aff, grid, st);
+  } else if (bm == 64 && bn == 128) {
+    if (p.mode == 1) gg3_launch<true, false, 2, 4>(p, aff, grid, st); else gg3_launch<false, true, 2, 4>(p, aff, grid, st);
+  } else {
+    if (p.mode == 1) gg3_launch<true, false, 4, 4>(p, aff, grid, st); else gg3_launch<false, true, 4, 4>(p, aff, grid, st);
+  }
   VEEX_CHECK_LAUNCH();
   return 0;
 }

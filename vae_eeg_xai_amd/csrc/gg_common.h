@@ -241,5 +241,6 @@ int veex_gg_bf16_v3_ok(const GGParams& p);                                     /
 int veex_launch_gather_gemm_bf16_v3(GGParams& p, int mtiles, int bm, hipStream_t st);
 int veex_gg_v3_ok(const GGParams& p);                                          // gather_gemm_v3.hip
 int veex_launch_gather_gemm_v3(GGParams& p, int mtiles, hipStream_t st);
+int veex_gg_v3_bm(const GGParams& p);                                          // tile rows the lean fp32 kernel uses
 
 #endif

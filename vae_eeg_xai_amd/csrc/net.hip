@@ -65,7 +65,7 @@ static inline int pow2_or_zero(int c) { return (c > 0 && (c & (c - 1)) == 0); }
 static int fill_gg(const VeexGemmDesc* d, GGParams& p) {
   if (d == nullptr) { veex_set_error("null descriptor"); return VEEX_EINVAL; }
   memset(&p, 0, sizeof(p));
-  p.A = d->in; p.W = d->weight; p.Wbf = d->weight_bf16; p.Out = d->out;
+  p.A = d->in; p.W = d->weight; p.Wbf = d->weight_bf16; p.Wt = (d->mode == 0) ? d->weight_t : nullptr; p.Out = d->out;
   p.Abf = d->in_bf16; p.OutBf = d->out_bf16; p.o_scale = d->out_scale; p.o_shift = d->out_shift;
   if (p.o_scale != nullptr) {
     if (!pow2_or_zero(d->out_channels) || p.o_shift == nullptr) { veex_set_error("gather_gemm: out_channels must be a power of two and out_shift non-null"); return VEEX_EINVAL; }
@@ -399,6 +399,7 @@ struct Plan {
   long long slab, slab_side, partials, partials2, losses_tmp;
   long long slab_n, partials_n, partials2_n;
   long long wpack[7][2];
+  long long wpackf[7];   // fp32 engine: transposed fp32 copy [tap][Cout_gemm][Cin_gemm] of the big kernels for their mode-0 launches
   // bf16 consumer copies (bf16 compute only; -1 otherwise): BatchNorm-applied activations and gradients
   long long bf_act_conv[2], bf_act_dd, bf_act_dc[4], bf_d_dc[5], bf_d_conv[3];   // bf16 weight copies (floats offset): layers conv2, conv3, deconv1..5; [0] as stored, [1] transposed
 };
@@ -519,6 +520,7 @@ static void make_plan(const VeexNet* n, int B, Plan& P) {
     const long long halfs = (long long)l.k * l.k * l.Cin * l.Cout;
     P.wpack[i][0] = w.add(std::string("wpack.") + l.name + ".a", (halfs + 1) / 2);
     P.wpack[i][1] = w.add(std::string("wpack.") + l.name + ".t", (halfs + 1) / 2);
+    P.wpackf[i] = w.add(std::string("wpackf.") + l.name, halfs);
   }
 }
 
@@ -550,6 +552,7 @@ struct Ctx {
   hipStream_t st;
   long long part_cur = 0;       // bump cursor into scratch.partials: every producer of one pass keeps its own rows
   ColsumBatch fin;              // column-sum finalisations collected during the backward pass (flush_colsum)
+  bool have_wt_enc = false, have_wt_bwd = false;   // packed fp32 weight copies made by this call (run_transpose_weights)
   // divisor of the batch mean (models.py:156-163): the local batch, or the caller's (a rank's share of a global batch)
   double div() const { return (n->batch_div > 0.0) ? n->batch_div : (double)B; }
   float inv_div() const { return (n->batch_div > 0.0) ? (float)(1.0 / n->batch_div) : 1.0f / B; }
@@ -569,6 +572,30 @@ static int check_common(const VeexNet* n, const void* params, const void* state,
 }
 
 // bf16 copies of the seven big kernels from the fp32 master weights (once per call: the weights change every step)
+// fp32 engine: transposed copies for the mode-0 launches of the lean kernel (the Conv2D forwards; with `bwd` also the
+// Conv2DTranspose input gradients), one launch per call -- the weights change every step
+static int run_transpose_weights(Ctx& c, bool enc, bool bwd) {
+  const float* src[7]; float* dst[7]; int taps[7], rows[7], cols[7];
+  int k = 0;
+  for (int i = 0; i < 7; ++i) {
+    const bool conv = i < 2;
+    if (conv ? !enc : !bwd) continue;
+    const ConvLayer& l = big_layer(c.n, i);
+    // Conv2D kernel (kh,kw,Cin,Cout): rows Cin; Conv2DTranspose kernel (kh,kw,Cout,Cin): rows Cout
+    src[k] = c.P + l.w; dst[k] = c.ws + c.plan.wpackf[i]; taps[k] = l.k * l.k;
+    rows[k] = conv ? l.Cin : l.Cout; cols[k] = conv ? l.Cout : l.Cin;
+    ++k;
+  }
+  c.have_wt_enc = enc; c.have_wt_bwd = bwd;
+  if (k == 0) return 0;
+  return veex_transpose_weights_f32_multi(k, src, dst, taps, rows, cols, c.st);
+}
+// the packed fp32 copy of big layer i, if this call made it
+static const float* packed_wt(const Ctx& c, int i) {
+  if (c.n->compute == VEEX_COMPUTE_BF16) return nullptr;
+  return ((i < 2) ? c.have_wt_enc : c.have_wt_bwd) ? c.ws + c.plan.wpackf[i] : nullptr;
+}
+
 static int run_pack_weights(Ctx& c) {
   if (c.n->compute != VEEX_COMPUTE_BF16) return 0;
   const float* src[14]; void* dst[14]; int taps[14], rows[14], cols[14], tr[14];
@@ -603,9 +630,10 @@ static int run_bn_prepare(Ctx& c) {
 
 // forward GEMM layer: in (with producer BN) -> out = relu?(conv + bias)
 static int fwd_gemm(Ctx& c, const ConvLayer& l, int mode, const float* in, int in_bn, int in_bnC, int aff_spatial,
-                    float* out, int relu, const void* wp = nullptr, const void* abf = nullptr, void* outbf = nullptr) {
+                    float* out, int relu, const void* wp = nullptr, const void* abf = nullptr, void* outbf = nullptr,
+                    const float* wt = nullptr) {
   GGParams p; memset(&p, 0, sizeof(p));
-  p.A = in; p.W = c.P + l.w; p.Wbf = wp; p.Out = out; p.bias = c.P + l.b;
+  p.A = in; p.W = c.P + l.w; p.Wbf = wp; p.Wt = wt; p.Out = out; p.bias = c.P + l.b;
   p.Abf = abf; p.OutBf = outbf;
   if (outbf != nullptr && l.bn >= 0) { p.o_scale = c.scale(l.bn); p.o_shift = c.shift(l.bn); p.o_cmask = l.bnC - 1; }
   if (in_bn >= 0) { p.a_scale = c.scale(in_bn); p.a_shift = c.shift(in_bn); p.aff_mask = in_bnC - 1; p.aff_spatial = aff_spatial; }
@@ -622,9 +650,9 @@ static int encoder_forward(Ctx& c, const float* x) {
   TRY(veex_conv1_fwd_bf16(x, c.P + n->conv[0].w, c.P + n->conv[0].b, ws + P.act_conv[0], c.scale(n->conv[0].bn),
                           c.shift(n->conv[0].bn), bfp(c, P.bf_act_conv[0]), c.B, c.st));
   TRY(fwd_gemm(c, n->conv[1], 0, ws + P.act_conv[0], n->conv[0].bn, 64, 0, ws + P.act_conv[1], 1, packed_w(c, 0, 1),
-               bfp(c, P.bf_act_conv[0]), bfp(c, P.bf_act_conv[1])));
+               bfp(c, P.bf_act_conv[0]), bfp(c, P.bf_act_conv[1]), packed_wt(c, 0)));
   TRY(fwd_gemm(c, n->conv[2], 0, ws + P.act_conv[1], n->conv[1].bn, 128, 0, ws + P.act_conv[2], 1, packed_w(c, 1, 1),
-               bfp(c, P.bf_act_conv[1]), nullptr));
+               bfp(c, P.bf_act_conv[1]), nullptr, packed_wt(c, 1)));
   {  // Dense(6400 -> H1, relu) as a 5x5 VALID conv, split-K over taps/channels
     const ConvLayer& l = n->dense;
     GGParams p; memset(&p, 0, sizeof(p));
@@ -734,7 +762,7 @@ static void deconv_dgrad_desc(Ctx& c, int i, GGParams& p) {
   const Plan& P = c.plan;
   const ConvLayer& l = n->dc[i];
   memset(&p, 0, sizeof(p));
-  p.A = c.ws + P.d_dc[i]; p.W = c.P + l.w; p.Wbf = packed_w(c, i + 2, 0);
+  p.A = c.ws + P.d_dc[i]; p.W = c.P + l.w; p.Wbf = packed_w(c, i + 2, 0); p.Wt = packed_wt(c, i + 2);
   p.Abf = bfp(c, P.bf_d_dc[i]); p.OutBf = (i > 0) ? bfp(c, P.bf_d_dc[i - 1]) : nullptr;
   p.Nb = c.B; p.Hin = p.Win = l.Hout; p.Cin = l.Cout; p.Hout = p.Wout = l.Hin; p.Cout = l.Cin;
   p.kh = p.kw = l.k; p.stride = l.stride; p.pb = l.pb; p.mode = 0;
@@ -882,6 +910,7 @@ extern "C" int veex_net_encode(const VeexNet* n, const float* params, const floa
   Ctx c; c.n = n; c.P = params; c.S = state; c.ws = ws; c.B = B; c.st = st;
   make_plan(n, B, c.plan);
   TRY(run_bn_prepare(c));
+  if (n->compute != VEEX_COMPUTE_BF16) TRY(run_transpose_weights(c, true, false));
   TRY(encode_impl(c, x, eps_io, flags, seed, first_sample, 0));
   const int L = n->L;
   if (n->variant == VEEX_VARIANT_VAE) {
@@ -920,6 +949,7 @@ extern "C" int veex_net_forward(const VeexNet* n, const float* params, const flo
   make_plan(n, B, c.plan);
   const Plan& P = c.plan;
   TRY(run_bn_prepare(c));
+  if (n->compute != VEEX_COMPUTE_BF16) TRY(run_transpose_weights(c, true, false));
   TRY(encode_impl(c, x, eps_io, flags, seed, first_sample, 1));
   const float* zdec = ws + P.z;
   if ((flags & VEEX_F_ZMEAN_DECODE) && n->variant == VEEX_VARIANT_VAE) {
@@ -948,6 +978,7 @@ extern "C" int veex_net_train_fwd_bwd(const VeexNet* n, const float* params, con
 
   // ---- forward (models.py:152-163) ----
   TRY(run_bn_prepare(c));
+  if (n->compute != VEEX_COMPUTE_BF16) TRY(run_transpose_weights(c, true, true));
   TRY(encode_impl(c, x, eps_io, flags, seed, first_sample, 1));
   TRY(decoder_trunk(c, ws + P.z));
   TRY(deconv6_forward(c, x, nullptr, nullptr, ws + P.dlogit, ws + P.rec_b, ws + P.dlsum_b));
@@ -1052,6 +1083,7 @@ extern "C" int veex_net_attribute(const VeexNet* n, const float* params, const f
   make_plan(n, B, c.plan);
   const Plan& P = c.plan;
   TRY(run_bn_prepare(c));
+  if (n->compute != VEEX_COMPUTE_BF16) TRY(run_transpose_weights(c, true, false));
   TRY(encoder_forward(c, x));
   const bool vae = (n->variant == VEEX_VARIANT_VAE);
   for (int u = 0; u < n_units; ++u) {

@@ -25,12 +25,32 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // ---------------------------------------------------------------------------------------
 // conv1: x [B][40][40] -> a1 [B][20][20][64] = relu(conv3x3 s2 SAME(pad 0/1) + bias)
-// thread = (pixel lane, 4 channels); 9x4 weights in registers; one float4 store per pixel.
+// One work unit = ten output rows of one sample (200 pixels): its 21 input rows are staged in LDS with coalesced
+// 16-byte loads, then thread = (pixel lane, 4 channels) walks 13 pixels, 9x4 weights in registers, taps read from LDS,
+// one float4 store per pixel.  HBM-bound on the 52 MB it writes; the first version read its nine taps from global
+// memory per pixel and was bound by that latency (20.6 us = 2.7 TB/s at batch 512, profiles/r01_seq_f32.txt).
 // ---------------------------------------------------------------------------------------
+#define C1_UROWS 10                       // output rows per unit
+#define C1_UPIX (C1_UROWS * C1H)          // 200 pixels per unit
+#define C1_IROWS (2 * C1_UROWS + 1)       // 21 input rows (the last one is the zero row below the image for the lower half)
+#define C1_LDW 44                         // padded LDS row: column 40 is the zero column right of the image
+
+// stage input rows [2*oy0, 2*oy0 + 21) of one 40x40 sample into xs[21][44]; rows / columns past the image are zeros
+__device__ __forceinline__ void conv1_stage(const float* __restrict__ xsrc, int oy0, float* __restrict__ xs) {
+  for (int i = threadIdx.x; i < C1_IROWS * (C1_LDW / 4); i += 256) {
+    const int r = i / (C1_LDW / 4), c4 = i - r * (C1_LDW / 4);
+    const int iy = 2 * oy0 + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (iy < IMG && c4 < IMG / 4) v = *reinterpret_cast<const float4*>(xsrc + iy * IMG + 4 * c4);
+    *reinterpret_cast<float4*>(xs + r * C1_LDW + 4 * c4) = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ out,
-                                                        int npix, const float* __restrict__ bscale,
+                                                        int nunits, const float* __restrict__ bscale,
                                                         const float* __restrict__ bshift, __bf16* __restrict__ out_bf) {
+  __shared__ __attribute__((aligned(16))) float xs[C1_IROWS * C1_LDW];
   const int cq = threadIdx.x & 15, pg = threadIdx.x >> 4;
   float4 w[9];
 #pragma unroll
@@ -41,75 +61,83 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     osc = *reinterpret_cast<const float4*>(bscale + 4 * cq);
     osh = *reinterpret_cast<const float4*>(bshift + 4 * cq);
   }
-  for (int pix = blockIdx.x * 16 + pg; pix < npix; pix += gridDim.x * 16) {
-    const int n = pix / (C1H * C1H), rem = pix - n * (C1H * C1H);
-    const int oy = rem / C1H, ox = rem - oy * C1H;
-    const float* xs = x + (long long)n * (IMG * IMG);
-    float4 acc = b4;
+  for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+    const int n = unit >> 1, oy0 = (unit & 1) * C1_UROWS;
+    __syncthreads();                       // the previous unit's taps have been read
+    conv1_stage(x + (long long)n * (IMG * IMG), oy0, xs);
+    __syncthreads();
+    const long long pix0 = (long long)n * (C1H * C1H) + oy0 * C1H;
+#pragma unroll 2
+    for (int lp = pg; lp < C1_UPIX; lp += 16) {
+      const int ry = lp / C1H, ox = lp - ry * C1H;
+      const float* t0 = xs + (2 * ry) * C1_LDW + 2 * ox;
+      float4 acc = b4;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = 2 * oy + ky;
+      for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = 2 * ox + kx;
-        const float v = (iy < IMG && ix < IMG) ? xs[iy * IMG + ix] : 0.f;
-        const float4 ww = w[ky * 3 + kx];
-        acc.x = fmaf(v, ww.x, acc.x); acc.y = fmaf(v, ww.y, acc.y);
-        acc.z = fmaf(v, ww.z, acc.z); acc.w = fmaf(v, ww.w, acc.w);
+        for (int kx = 0; kx < 3; ++kx) {
+          const float v = t0[ky * C1_LDW + kx];
+          const float4 ww = w[ky * 3 + kx];
+          acc.x = fmaf(v, ww.x, acc.x); acc.y = fmaf(v, ww.y, acc.y);
+          acc.z = fmaf(v, ww.z, acc.z); acc.w = fmaf(v, ww.w, acc.w);
+        }
       }
-    }
-    acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
-    *reinterpret_cast<float4*>(out + (long long)pix * NCH + 4 * cq) = acc;
-    if (out_bf != nullptr) {
-      bf16x4_t h;
-      h[0] = (__bf16)fmaf(acc.x, osc.x, osh.x); h[1] = (__bf16)fmaf(acc.y, osc.y, osh.y);
-      h[2] = (__bf16)fmaf(acc.z, osc.z, osh.z); h[3] = (__bf16)fmaf(acc.w, osc.w, osh.w);
-      *reinterpret_cast<bf16x4_t*>(out_bf + (long long)pix * NCH + 4 * cq) = h;
+      acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+      *reinterpret_cast<float4*>(out + (pix0 + lp) * NCH + 4 * cq) = acc;
+      if (out_bf != nullptr) {
+        bf16x4_t h;
+        h[0] = (__bf16)fmaf(acc.x, osc.x, osh.x); h[1] = (__bf16)fmaf(acc.y, osc.y, osh.y);
+        h[2] = (__bf16)fmaf(acc.z, osc.z, osh.z); h[3] = (__bf16)fmaf(acc.w, osc.w, osh.w);
+        *reinterpret_cast<bf16x4_t*>(out_bf + (pix0 + lp) * NCH + 4 * cq) = h;
+      }
     }
   }
 }
 
-// dW1[tap][co] partials: slab[block][9][64]
+// dW1[tap][co] partials: slab[block][9][64].  Same units and LDS staging as conv1_fwd; the only global loads of
+// the pixel loop are the float4 gradients, four of them in flight per thread.
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dpre,
-                                                          float* __restrict__ slab, int npix) {
-  __shared__ __attribute__((aligned(16))) float red[16 * 9 * NCH];
+                                                          float* __restrict__ slab, int nunits) {
+  __shared__ __attribute__((aligned(16))) float red[16 * 9 * NCH];     // also the staged input rows (21 x 44 floats)
+  float* xs = red;
   const int cq = threadIdx.x & 15, pg = threadIdx.x >> 4;
   float4 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-  // two pixels per trip (25 dependent trips per thread otherwise): both gradients and 2 x 9 inputs in flight
-  const int pstride = gridDim.x * 16;
-  for (int pix0 = blockIdx.x * 16 + pg; pix0 < npix; pix0 += 2 * pstride) {
-    float v[2][9];
-    float4 g[2];
+  constexpr int TRIPS = (C1_UPIX + 15) / 16;     // 13 pixels per thread and unit, the last trip half empty
+  for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+    const int n = unit >> 1, oy0 = (unit & 1) * C1_UROWS;
+    const float* gsrc = dpre + ((long long)n * (C1H * C1H) + oy0 * C1H) * NCH + 4 * cq;
+    float4 g[4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int pix = pix0 + u * pstride;
-      const bool live = pix < npix;
-      const int n = pix / (C1H * C1H), rem = pix - n * (C1H * C1H);
-      const int oy = rem / C1H, ox = rem - oy * C1H;
-      const float* xs = x + (long long)n * (IMG * IMG);
-      g[u] = live ? *reinterpret_cast<const float4*>(dpre + (long long)pix * NCH + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < 4; ++u) g[u] = *reinterpret_cast<const float4*>(gsrc + (long long)(pg + 16 * u) * NCH);
+    __syncthreads();
+    conv1_stage(x + (long long)n * (IMG * IMG), oy0, xs);
+    __syncthreads();
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int iy = 2 * oy + ky;
+    for (int tr = 0; tr < TRIPS; ++tr) {
+      const int lp = pg + 16 * tr;
+      const float4 gc = g[tr & 3];
+      if (tr + 4 < TRIPS) {
+        const int lq = lp + 64;
+        g[tr & 3] = (lq < C1_UPIX) ? *reinterpret_cast<const float4*>(gsrc + (long long)lq * NCH) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (lp < C1_UPIX) {
+        const int ry = lp / C1H, ox = lp - ry * C1H;
+        const float* t0 = xs + (2 * ry) * C1_LDW + 2 * ox;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int ix = 2 * ox + kx;
-          v[u][ky * 3 + kx] = (live && iy < IMG && ix < IMG) ? xs[iy * IMG + ix] : 0.f;
+        for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const float v = t0[ky * C1_LDW + kx];
+            float4& a = acc[ky * 3 + kx];
+            a.x = fmaf(v, gc.x, a.x); a.y = fmaf(v, gc.y, a.y); a.z = fmaf(v, gc.z, a.z); a.w = fmaf(v, gc.w, a.w);
+          }
         }
       }
     }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        float4& a = acc[t];
-        a.x = fmaf(v[u][t], g[u].x, a.x); a.y = fmaf(v[u][t], g[u].y, a.y);
-        a.z = fmaf(v[u][t], g[u].z, a.z); a.w = fmaf(v[u][t], g[u].w, a.w);
-      }
-    }
   }
+  __syncthreads();
 #pragma unroll
   for (int t = 0; t < 9; ++t) *reinterpret_cast<float4*>(red + (pg * 9 + t) * NCH + 4 * cq) = acc[t];
   __syncthreads();
@@ -814,18 +842,17 @@ int veex_conv1_fwd(const float* x, const float* W, const float* bias, float* out
 int veex_conv1_fwd_bf16(const float* x, const float* W, const float* bias, float* out, const float* bn_scale,
                         const float* bn_shift, void* out_bf16, int B, hipStream_t st) {
   if (out_bf16 != nullptr && (bn_scale == nullptr || bn_shift == nullptr)) { veex_set_error("conv1_fwd: bf16 copy needs the BatchNorm affine"); return -1; }
-  const int npix = B * C1H * C1H;
-  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(grid_for(npix, 16, 4096)), dim3(256), 0, st, x, W, bias, out, npix, bn_scale,
+  const int nunits = 2 * B;    // ten output rows of one sample each
+  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(grid_for(nunits, 1, 2048)), dim3(256), 0, st, x, W, bias, out, nunits, bn_scale,
                      bn_shift, reinterpret_cast<__bf16*>(out_bf16));
   VEEX_CHECK_LAUNCH();
   return 0;
 }
 
-int veex_conv1_wgrad_blocks(int B) { return grid_for((long long)B * C1H * C1H, 16 * 16, 512); }
+int veex_conv1_wgrad_blocks(int B) { return grid_for(2LL * B, 1, 1024); }   // units of ten output rows; at most 1024 slab rows
 
 int veex_conv1_wgrad(const float* x, const float* dpre, float* slab, int B, hipStream_t st) {
-  const int npix = B * C1H * C1H;
-  hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(veex_conv1_wgrad_blocks(B)), dim3(256), 0, st, x, dpre, slab, npix);
+  hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(veex_conv1_wgrad_blocks(B)), dim3(256), 0, st, x, dpre, slab, 2 * B);
   VEEX_CHECK_LAUNCH();
   return 0;
 }

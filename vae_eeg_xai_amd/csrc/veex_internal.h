@@ -21,6 +21,8 @@ struct GGParams {
   const float* A;        // gathered operand, NHWC [Nb][Hin][Win][Cin]
   const float* W;
   const void* Wbf;        // optional packed bf16 weights [tap][Cout][Cin]: run the bf16-MFMA kernel
+  const float* Wt;        // optional fp32 copy of W as [tap][Cout][Cin] for a MODE 0 launch of the lean fp32 kernel (whose
+                          // B fragment then is one 16-byte LDS read per four MFMAs, like mode 1, instead of four 4-byte ones)
   float* Out;            // NHWC [Nb][Hout][Wout][Cout]; RAW: slab base [nsplit][same]
   const float* a_scale;  // optional per-channel affine applied to in-bounds A loads (producer's BN)
   const float* a_shift;
@@ -131,6 +133,9 @@ extern "C" int veex_deconv6_bwd_bf16(const float* dlogit, const float* a5, const
 int veex_pack_weights_bf16_multi(int n, const float* const* src, void* const* dst, const int* taps, const int* rows,
                                  const int* cols, const int* transpose, hipStream_t st);
 extern "C" int veex_pack_weights_bf16(const float* src, void* dst, int taps, int rows, int cols, int transpose, hipStream_t st);
+// fp32 transposed copies dst[tap][c][r] = src[tap][r][c] of up to 16 kernels in one launch (GGParams::Wt)
+int veex_transpose_weights_f32_multi(int n, const float* const* src, float* const* dst, const int* taps, const int* rows,
+                                     const int* cols, hipStream_t st);
 
 void veex_set_error(const char* fmt, ...);
 

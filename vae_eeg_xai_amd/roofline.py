@@ -71,6 +71,15 @@ def _pack(W, transpose):
     return dst
 
 
+def _transposed(W):
+    """fp32 copy [tap][cols][rows] of a (k,k,rows,cols) kernel (veex_transpose_weights_f32), as the whole-step entry
+    points make for the mode-0 launches of the lean fp32 kernel."""
+    k, _, rows, cols = W.shape
+    dst = torch.empty(W.numel(), dtype=torch.float32, device="cuda")
+    check(lib.veex_transpose_weights_f32(_lib.ptr(W), _lib.ptr(dst), k * k, rows, cols, _lib.current_stream()), "transpose")
+    return dst
+
+
 def gemm_cases(B, bf16=False):
     """Yield (label, macs, launch_fn) for every MFMA launch of one train step at batch B."""
     stream = _lib.current_stream
@@ -80,6 +89,8 @@ def gemm_cases(B, bf16=False):
            aux=None, esc=None, wbf=None, osc=None):
         d = GemmDesc()
         d.inp, d.weight, d.out = A.data_ptr(), W.data_ptr(), out.data_ptr()
+        if wbf is None and mode == 0:
+            wt = _transposed(W); keep.append(wt); d.weight_t = wt.data_ptr()
         if wbf is not None:
             keep.append(wbf); d.weight_bf16 = wbf.data_ptr()
             # bf16 consumer copies as the network uses them: A with its BatchNorm applied, Out copy for the next layer
