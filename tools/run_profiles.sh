@@ -9,7 +9,6 @@ mkdir -p $O
 timeout -k 10 300 python bench.py --steps 50 --warmup 10 > $O/bench.json 2> $O/bench.err
 timeout -k 10 120 python -m vae_eeg_xai_amd.roofline 512 > $O/layer_table.txt 2>/dev/null
 timeout -k 10 300 python bench.py --dtype bf16 --steps 50 --warmup 10 --no-cpu-baseline > $O/bench_bf16.json 2> $O/bench_bf16.err
-timeout -k 10 120 python -m vae_eeg_xai_amd.roofline 512 bf16 > $O/layer_table_bf16.txt 2>/dev/null
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-attribution > $O/trace.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python tools/prof_gemms.py 512 2 > $O/pmc_fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python tools/prof_gemms.py 512 2 > $O/pmc_write.log 2>&1
@@ -19,5 +18,16 @@ bash tools/prof_seq.sh $R/seq_f32 > $O/seq_f32.txt 2>&1
 bash tools/prof_seq.sh $R/seq_bf16 --dtype bf16 > $O/seq_bf16.txt 2>&1
 # attribution only (batch 4096: 3 x top-1 unit, 3 x all 28 units)
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/attr -- python tools/prof_attr.py > $O/attr.log 2>&1
-timeout -k 10 60 tools/micro/mfma_issue > $O/micro_mfma_issue.txt 2>&1
+[ -x tools/micro/mfma_issue ] && timeout -k 10 60 tools/micro/mfma_issue > $O/micro_mfma_issue.txt 2>&1
+# HBM-bound kernels: achieved GB/s against 8 TB/s
+timeout -k 10 200 python -m vae_eeg_xai_amd.roofline --hbm 512 > $O/hbm_table.txt 2>/dev/null
+# bf16 engine: counter passes of their own (tools/pmc_bf16.sh writes $O/pmc_*_bf16)
+bash tools/pmc_bf16.sh $R > $O/pmc_bf16.log 2>&1
+# two ranks on the one GPU, collectives staged through the host (gloo): the N > 1 control flow of bench.py
+VEEX_DIST_BACKEND=gloo VEEX_DIST_ONE_GPU=1 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
+  --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 10 --warmup 3 --no-roofline > $O/dp2_rehearsal.json 2> $O/dp2_rehearsal.err
+# latent sweep of configs[2] at its local batch (one GPU)
+for L in 2 8 16 28 64 128; do
+  timeout -k 10 200 python bench.py --batch 1024 --latent $L --steps 30 --warmup 10 --no-cpu-baseline --no-roofline --no-attribution 2>/dev/null >> $O/latent_sweep_b1024.jsonl
+done
 echo PROFILES_DONE

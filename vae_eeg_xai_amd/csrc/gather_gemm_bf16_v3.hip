@@ -338,7 +338,7 @@ int veex_launch_gather_gemm_bf16_v3(GGParams& p, int mtiles, int bm, hipStream_t
   unsigned blocks = (unsigned)ntiles * mtiles;
   // one image row per tile group wherever a launch has vertically padded taps to skip
   const bool vpad = (p.mode == 1) ? true : (p.pb > 0 || (p.Hout - 1) * p.stride + p.kh - 1 - p.pb >= p.Hin);
-  p.row_order = (p.kh > 1 && vpad) ? veex_env_int("VEEX_ROWORD", 1) : 0;
+  p.row_order = (p.kh > 1 && vpad) ? (veex_env_int("VEEX_ROWORD", 1) != 0 ? 1 : 0) : 0;
   if (p.row_order == 1 && xr < 0) {
     const long long rowlen = (long long)p.Nb * p.Wout;
     p.remap = 0;

@@ -72,7 +72,8 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
   if (p.remap == 2) {
     // row_order 1, one phase: the tiles (image row y, sample group g) of ALL y go to XCD g % 8 (workgroups are dealt
     // round-robin over the XCDs), in y-major order: a sample group's input rows are shared by three consecutive
-    // output rows, and meet in ONE L2 (deconv4 forward: 291 -> 94 MB fetched, -11 % time vs the chunked order)
+    // output rows, and meet in ONE L2 (deconv4 forward: 291 -> 94 MB fetched, -11 % time vs the chunked order).
+    // row_order 2 (any number of phases): the same with "output pixel" in place of "image row": tile = pixel * G + g
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
     const int rest = local / p.gx, gq = p.row_tiles >> 3;
     bnt = local - rest * p.gx;
@@ -107,15 +108,18 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
   }
   const int cpt = p.Cin / BK;
   const int ntaps = nky * nkx;
-  // row m of the phase -> (sample n, phase row j, phase column i): (n, j, i) order, or (j, n, i) with row_order 1
+  // row m of the phase -> (sample n, phase row j, phase column i): (n, j, i) order, (j, n, i) with row_order 1,
+  // (j, i, n) with row_order 2
   const int D1 = p.row_order ? p.Nb * Wp : Hp * Wp;
-  const float invD1 = 1.0f / (float)D1, invWp = 1.0f / (float)Wp;   // rows < 2^24 (veex_gg_v3_ok)
+  const int D2 = (p.row_order == 2) ? p.Nb : Wp;
+  const float invD1 = 1.0f / (float)D1, invD2 = 1.0f / (float)D2;   // rows < 2^24 (veex_gg_v3_ok)
   auto row_nji = [&](int m, int& n, int& j, int& i) {
-    int a, rem, b;
+    int a, rem, b, c;
     g3_divmod(m, D1, invD1, a, rem);
-    g3_divmod(rem, Wp, invWp, b, i);
-    n = p.row_order ? b : a;
-    j = p.row_order ? a : b;
+    g3_divmod(rem, D2, invD2, b, c);
+    if (p.row_order == 2)      { j = a; i = b; n = c; }
+    else if (p.row_order == 1) { j = a; n = b; i = c; }
+    else                       { n = a; j = b; i = c; }
   };
 
   if (tid == 0) *s_tmk = 0u;
@@ -457,7 +461,18 @@ int veex_launch_gather_gemm_v3(GGParams& p, int mtiles, hipStream_t st) {
   // one image row per tile wherever a launch has vertically padded taps to skip (A/B at batch 512: -2...-8 % on
   // those launches, +3 % on a launch without padding, whose tiles then only lose locality)
   const bool vpad = (p.mode == 1) ? true : (p.pb > 0 || (p.Hout - 1) * p.stride + p.kh - 1 - p.pb >= p.Hin);
-  p.row_order = (p.kh > 1 && p.nsplit == 1 && vpad) ? veex_env_int("VEEX_ROWORD", 1) : 0;
+  const int ro = veex_env_int("VEEX_ROWORD", 2);
+  p.row_order = (p.kh > 1 && p.nsplit == 1 && vpad) ? (ro > 1 ? 1 : ro) : 0;
+  // one output PIXEL per tile (its rows = bm consecutive samples) when the batch is a multiple of the tile height:
+  // every row of the tile then has the same valid taps, vertically AND horizontally, and the tile executes exactly
+  // the in-bounds taps (deconv4 forward: 2 601 tap-pixels instead of the 2 907 that vertical skipping leaves)
+  if (p.row_order == 1 && ro == 2 && p.Nb % bm == 0 && mtiles % (p.Nb / bm) == 0) {
+    p.row_order = 2;
+    if (xr < 0) {
+      p.remap = 0;
+      if ((p.Nb / bm) % 8 == 0) { p.remap = 2; p.row_tiles = p.Nb / bm; }
+    }
+  }
   if (p.row_order == 1 && xr < 0) {
     // the chunked XCD order would split a sample group's image rows over the XCDs: group-per-XCD order where the
     // tiles line up with the image rows, plain round-robin otherwise
