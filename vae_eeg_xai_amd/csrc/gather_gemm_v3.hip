@@ -97,7 +97,19 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
   const int ostep = (p.nphase == 4) ? 2 : 1;
   const int oy0 = p.o0[py], ox0 = p.o0[px];
   const int Mph = p.Nb * Hp * Wp;
-  const int m0 = (tile - p.tile_prefix[ph]) * BM;
+  int m0 = (tile - p.tile_prefix[ph]) * BM;
+  if (p.row_order == 3) {
+    // one pixel per tile, pixels visited centre-out in y and in x: the tiles with the most valid taps are dispatched
+    // first and the short border tiles fill the tail of the launch (tile lengths differ 9:1 here)
+    const int t = tile - p.tile_prefix[ph], G = p.row_tiles;
+    int pix, g, yi, xi;
+    g3_divmod(t, G, 1.0f / (float)G, pix, g);
+    g3_divmod(pix, Wp, 1.0f / (float)Wp, yi, xi);
+    const int cy = (Hp - 1) >> 1, cx = (Wp - 1) >> 1;
+    const int y = (yi & 1) ? cy + ((yi + 1) >> 1) : cy - (yi >> 1);
+    const int x = (xi & 1) ? cx + ((xi + 1) >> 1) : cx - (xi >> 1);
+    m0 = __builtin_amdgcn_readfirstlane(((y * Wp + x) * G + g) * BM);
+  }
   const int n0 = bnt * BN;
 
   int kys = 0, kxs = 0, kstep = 1, nky = p.kh, nkx = p.kw;
@@ -109,15 +121,15 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
   const int cpt = p.Cin / BK;
   const int ntaps = nky * nkx;
   // row m of the phase -> (sample n, phase row j, phase column i): (n, j, i) order, (j, n, i) with row_order 1,
-  // (j, i, n) with row_order 2
+  // (j, i, n) with row_order 2 / 3
   const int D1 = p.row_order ? p.Nb * Wp : Hp * Wp;
-  const int D2 = (p.row_order == 2) ? p.Nb : Wp;
+  const int D2 = (p.row_order >= 2) ? p.Nb : Wp;
   const float invD1 = 1.0f / (float)D1, invD2 = 1.0f / (float)D2;   // rows < 2^24 (veex_gg_v3_ok)
   auto row_nji = [&](int m, int& n, int& j, int& i) {
     int a, rem, b, c;
     g3_divmod(m, D1, invD1, a, rem);
     g3_divmod(rem, D2, invD2, b, c);
-    if (p.row_order == 2)      { j = a; i = b; n = c; }
+    if (p.row_order >= 2)      { j = a; i = b; n = c; }
     else if (p.row_order == 1) { j = a; n = b; i = c; }
     else                       { n = a; j = b; i = c; }
   };
@@ -467,7 +479,10 @@ int veex_launch_gather_gemm_v3(GGParams& p, int mtiles, hipStream_t st) {
   // every row of the tile then has the same valid taps, vertically AND horizontally, and the tile executes exactly
   // the in-bounds taps (deconv4 forward: 2 601 tap-pixels instead of the 2 907 that vertical skipping leaves)
   if (p.row_order == 1 && ro == 2 && p.Nb % bm == 0 && mtiles % (p.Nb / bm) == 0) {
-    p.row_order = 2;
+    // centre-out only for one-phase launches (A/B at batch 512: -2...-6 % there; the 4-phase launches, whose phases
+    // already run longest first, lose locality: +2...+7 %)
+    p.row_order = (p.nphase == 1 && veex_env_int("VEEX_TILEPERM", 1)) ? 3 : 2;
+    p.row_tiles = p.Nb / bm;
     if (xr < 0) {
       p.remap = 0;
       if ((p.Nb / bm) % 8 == 0) { p.remap = 2; p.row_tiles = p.Nb / bm; }

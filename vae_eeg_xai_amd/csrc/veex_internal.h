@@ -53,9 +53,10 @@ struct GGParams {
   const float* o_shift;
   int o_cmask;           // o_scale index = col & o_cmask
   int row_order;         // lean fp32 kernel: 0 = tile rows run over (n, y, x), 1 = over (y, n, x) -- one image row per tile,
-                         // 2 = over (y, x, n) with Nb % tile rows == 0 -- one output pixel per tile
-  int row_tiles;         // remap == 2: m tiles per image row (row_order 1) / per pixel (row_order 2), a multiple of 8; XCD x
-                         // owns the tiles g % 8 == x of every row / pixel
+                         // 2 = over (y, x, n) with Nb % tile rows == 0 -- one output pixel per tile, 3 = the same with the
+                         // pixels of a phase visited centre-out (longest tiles first)
+  int row_tiles;         // m tiles per image row (row_order 1, remap 2) / per pixel (row_order 2, 3); with remap == 2 a multiple
+                         // of 8: XCD x owns the tiles g % 8 == x of every row / pixel
 };
 
 // ---------------------------------------------------------------------------
