@@ -85,6 +85,10 @@ typedef struct VeexGemmDesc {
                               bf16-MFMA kernel (fp32 accumulate) when Cin % 32 == 0 and N*Hout*Wout >= 4096 */
   const float* weight_t;   /* optional, mode 0, fp32 engine: the same weights as [tap][Cout][Cin] (veex_transpose_weights_f32);
                               same result bit for bit, the kernel's weight fragment then is one 16-byte LDS read */
+  float* out_bn;           /* optional, epilogue 0: also write the fp32 copy out_scale[c]*out + out_shift[c] (this layer's
+                              BatchNorm applied once by the producer): the fp32 GEMMs that consume the activation then
+                              take it as `in` / `small` / `big` WITHOUT in_scale / in_shift -- same values bit for bit,
+                              8 of 15 vector instructions less per K chunk of the consumer */
 } VeexGemmDesc;
 int veex_gather_gemm(const VeexGemmDesc* d, veexStream_t stream);
 /* bf16 copy of one layer's kernel for veex_gather_gemm: src fp32 [taps][rows][cols] ->
@@ -126,6 +130,10 @@ int veex_conv1_fwd(const float* x, const float* w, const float* bias, float* out
 /* same, also writing the bf16 consumer copy bf16(bn_scale*out + bn_shift) that a bf16 conv2 reads (nullable) */
 int veex_conv1_fwd_bf16(const float* x, const float* w, const float* bias, float* out, const float* bn_scale,
                         const float* bn_shift, void* out_bf16, int batch, veexStream_t s);
+/* same with both optional consumer copies: out_bn = fp32 bn_scale*out + bn_shift (what an fp32 conv2 and its weight
+ * gradient read without an affine prologue), out_bf16 as above */
+int veex_conv1_fwd_copies(const float* x, const float* w, const float* bias, float* out, const float* bn_scale,
+                          const float* bn_shift, float* out_bn, void* out_bf16, int batch, veexStream_t s);
 int veex_conv1_wgrad_blocks(int batch);
 int veex_conv1_wgrad(const float* x, const float* dpre, float* slab /*[blocks][576]*/, int batch, veexStream_t s);
 /* d/dx through conv1 (attribution; no reference call site); mul != NULL gives gradient*input */

@@ -33,7 +33,7 @@ class GemmDesc(C.Structure):
         ("epilogue", C.c_int32), ("relu", C.c_int32), ("e_channels", C.c_int32), ("nsplit", C.c_int32),
         ("in_bf16", C.c_void_p), ("out_bf16", C.c_void_p), ("out_scale", C.c_void_p), ("out_shift", C.c_void_p),
         ("out_channels", C.c_int32), ("reserved_", C.c_int32),
-        ("weight_bf16", C.c_void_p), ("weight_t", C.c_void_p),
+        ("weight_bf16", C.c_void_p), ("weight_t", C.c_void_p), ("out_bn", C.c_void_p),
     ]
 
 
@@ -70,6 +70,7 @@ SIGNATURES = {
     "veex_wgrad_plan": (_I, [C.POINTER(WgradDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "veex_conv1_fwd": (_I, [_P, _P, _P, _P, _I, _P]),
     "veex_conv1_fwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "veex_conv1_fwd_copies": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "veex_conv1_wgrad_blocks": (_I, [_I]),
     "veex_conv1_wgrad": (_I, [_P, _P, _P, _I, _P]),
     "veex_conv1_dgrad": (_I, [_P, _P, _P, _P, _I, _P]),

@@ -339,6 +339,10 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
   if (colok) {
     if (p.epi == VEEX_EPI_FWD) {
       const float bia = (p.bias != nullptr) ? p.bias[col] : 0.f;
+      // the BatchNorm-applied copy for the fp32 consumers of this activation (zero records without one: stores dropped)
+      const bool has_bn = p.OutBn != nullptr;
+      const __amdgpu_buffer_rsrc_t rN = __builtin_amdgcn_make_buffer_rsrc(has_bn ? p.OutBn : outp, 0, has_bn ? (int)out_bytes : 0, 0x00020000);
+      const float osc = has_bn ? p.o_scale[col & p.o_cmask] : 1.f, osh = has_bn ? p.o_shift[col & p.o_cmask] : 0.f;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const uint4 ro = *reinterpret_cast<const uint4*>(s_offb + wm * 32 + 8 * g + 4 * lh);
@@ -348,6 +352,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
           float v = acc[4 * g + e] + bia;
           if (p.relu) v = fmaxf(v, 0.f);
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rO, rof[e] + col4, 0, 0);
+          if (has_bn) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaf(v, osc, osh)), rN, rof[e] + col4, 0, 0);
         }
       }
     } else if (p.epi == VEEX_EPI_BWD) {

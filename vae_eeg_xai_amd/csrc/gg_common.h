@@ -47,7 +47,7 @@ __device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[BM 
     if (colok) {
       if (p.epi == VEEX_EPI_FWD && p.bias != nullptr) bia = p.bias[col];
       if (p.epi == VEEX_EPI_BWD && p.e_scale != nullptr) esc = p.e_scale[col & p.epi_cmask];
-      if (obf != nullptr && p.epi == VEEX_EPI_FWD && p.o_scale != nullptr) { osc = p.o_scale[col & p.o_cmask]; osh = p.o_shift[col & p.o_cmask]; }
+      if ((obf != nullptr || p.OutBn != nullptr) && p.epi == VEEX_EPI_FWD && p.o_scale != nullptr) { osc = p.o_scale[col & p.o_cmask]; osh = p.o_shift[col & p.o_cmask]; }
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -63,6 +63,7 @@ __device__ __forceinline__ void gg_epilogue(const GGParams& p, f32x16 (&acc)[BM 
           if (p.relu) v = fmaxf(v, 0.f);
           outp[addr] = v;
           if (obf != nullptr) obf[addr] = (__bf16)fmaf(v, osc, osh);
+          if (p.OutBn != nullptr) p.OutBn[addr] = fmaf(v, osc, osh);
         } else if (p.epi == VEEX_EPI_BWD) {
           const float a = p.aux[addr];
           const bool on = (!p.relu) || (a > 0.f);
@@ -138,6 +139,8 @@ __device__ __forceinline__ void gg_epilogue_b(const GGParams& p, f32x16 (&acc)[B
                                                                       has_bf ? (int)(out_bytes >> 1) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.epi == VEEX_EPI_BWD ? p.aux : outp), 0, p.epi == VEEX_EPI_BWD ? (int)out_bytes : 0, 0x00020000);
+  const bool has_bn = (p.epi == VEEX_EPI_FWD) && (p.OutBn != nullptr);
+  const __amdgpu_buffer_rsrc_t rN = __builtin_amdgcn_make_buffer_rsrc(has_bn ? p.OutBn : outp, 0, has_bn ? (int)out_bytes : 0, 0x00020000);
 
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -147,7 +150,7 @@ __device__ __forceinline__ void gg_epilogue_b(const GGParams& p, f32x16 (&acc)[B
     float bia = 0.f, esc = 1.f, osc = 1.f, osh = 0.f;
     if (p.epi == VEEX_EPI_FWD && p.bias != nullptr) bia = p.bias[col];
     if (p.epi == VEEX_EPI_BWD && p.e_scale != nullptr) esc = p.e_scale[col & p.epi_cmask];
-    if (has_bf && p.epi == VEEX_EPI_FWD && p.o_scale != nullptr) { osc = p.o_scale[col & p.o_cmask]; osh = p.o_shift[col & p.o_cmask]; }
+    if ((has_bf || has_bn) && p.epi == VEEX_EPI_FWD && p.o_scale != nullptr) { osc = p.o_scale[col & p.o_cmask]; osh = p.o_shift[col & p.o_cmask]; }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -164,6 +167,7 @@ __device__ __forceinline__ void gg_epilogue_b(const GGParams& p, f32x16 (&acc)[B
               const __bf16 h = (__bf16)fmaf(v, osc, osh);
               __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), rB, (rof[e] >> 1) + col2, 0, 0);
             }
+            if (has_bn) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaf(v, osc, osh)), rN, rof[e] + col4, 0, 0);
           }
         } else if (p.epi == VEEX_EPI_BWD) {
           float a[4];

@@ -67,6 +67,8 @@ static int fill_gg(const VeexGemmDesc* d, GGParams& p) {
   memset(&p, 0, sizeof(p));
   p.A = d->in; p.W = d->weight; p.Wbf = d->weight_bf16; p.Wt = (d->mode == 0) ? d->weight_t : nullptr; p.Out = d->out;
   p.Abf = d->in_bf16; p.OutBf = d->out_bf16; p.o_scale = d->out_scale; p.o_shift = d->out_shift;
+  p.OutBn = (d->epilogue == VEEX_EPI_FWD) ? d->out_bn : nullptr;
+  if (p.OutBn != nullptr && p.o_scale == nullptr) { veex_set_error("gather_gemm: out_bn needs out_scale / out_shift"); return VEEX_EINVAL; }
   if (p.o_scale != nullptr) {
     if (!pow2_or_zero(d->out_channels) || p.o_shift == nullptr) { veex_set_error("gather_gemm: out_channels must be a power of two and out_shift non-null"); return VEEX_EINVAL; }
     p.o_cmask = d->out_channels - 1;
@@ -401,6 +403,8 @@ struct Plan {
   long long wpack[7][2];
   long long wpackf[7];   // fp32 engine: transposed fp32 copy [tap][Cout_gemm][Cin_gemm] of the big kernels for their mode-0 launches
   // bf16 consumer copies (bf16 compute only; -1 otherwise): BatchNorm-applied activations and gradients
+  // fp32 engine: BatchNorm-applied fp32 copies of the activations a GEMM consumes (GGParams::OutBn); -1 in bf16 mode
+  long long bn_conv[3], bn_dd, bn_dc[4];
   long long bf_act_conv[2], bf_act_dd, bf_act_dc[4], bf_d_dc[5], bf_d_conv[3];   // bf16 weight copies (floats offset): layers conv2, conv3, deconv1..5; [0] as stored, [1] transposed
 };
 
@@ -507,6 +511,13 @@ static void make_plan(const VeexNet* n, int B, Plan& P) {
   for (int i = 0; i < 4; ++i) P.bf_act_dc[i] = -1;
   for (int i = 0; i < 5; ++i) P.bf_d_dc[i] = -1;
   for (int i = 0; i < 3; ++i) P.bf_d_conv[i] = -1;
+  P.bn_conv[0] = P.bn_conv[1] = P.bn_conv[2] = P.bn_dd = -1;
+  for (int i = 0; i < 4; ++i) P.bn_dc[i] = -1;
+  if (n->compute != VEEX_COMPUTE_BF16) {
+    for (int i = 0; i < 3; ++i) P.bn_conv[i] = w.add(std::string("bn.") + n->conv[i].name, act_floats(n->conv[i], B));
+    P.bn_dd = w.add("bn.dec.dense", (long long)B * 4096);
+    for (int i = 0; i < 4; ++i) P.bn_dc[i] = w.add(std::string("bn.") + n->dc[i].name, act_floats(n->dc[i], B));
+  }
   if (n->compute == VEEX_COMPUTE_BF16) {
     auto half = [](long long elems) { return (elems + 1) / 2; };
     for (int i = 0; i < 2; ++i) P.bf_act_conv[i] = w.add(std::string("bf.act.") + n->conv[i].name, half(act_floats(n->conv[i], B)));
@@ -620,6 +631,8 @@ static const void* packed_w(const Ctx& c, int i, int fwd) {
 
 // pointer to a bf16 consumer copy region (nullptr in fp32 mode)
 static void* bfp(const Ctx& c, long long off) { return (off < 0) ? nullptr : static_cast<void*>(c.ws + off); }
+// pointer to a BatchNorm-applied fp32 copy (nullptr in bf16 mode, or with VEEX_BNCOPY=0: consumers then apply the affine)
+static float* bnp(const Ctx& c, long long off) { return (off < 0 || !veex_env_int("VEEX_BNCOPY", 1)) ? nullptr : c.ws + off; }
 
 static int run_bn_prepare(Ctx& c) {
   TRY(run_pack_weights(c));
@@ -631,11 +644,13 @@ static int run_bn_prepare(Ctx& c) {
 // forward GEMM layer: in (with producer BN) -> out = relu?(conv + bias)
 static int fwd_gemm(Ctx& c, const ConvLayer& l, int mode, const float* in, int in_bn, int in_bnC, int aff_spatial,
                     float* out, int relu, const void* wp = nullptr, const void* abf = nullptr, void* outbf = nullptr,
-                    const float* wt = nullptr) {
+                    const float* wt = nullptr, const float* in_bncopy = nullptr, float* out_bncopy = nullptr) {
   GGParams p; memset(&p, 0, sizeof(p));
   p.A = in; p.W = c.P + l.w; p.Wbf = wp; p.Wt = wt; p.Out = out; p.bias = c.P + l.b;
   p.Abf = abf; p.OutBf = outbf;
-  if (outbf != nullptr && l.bn >= 0) { p.o_scale = c.scale(l.bn); p.o_shift = c.shift(l.bn); p.o_cmask = l.bnC - 1; }
+  if (l.bn >= 0) p.OutBn = out_bncopy;
+  if ((outbf != nullptr || p.OutBn != nullptr) && l.bn >= 0) { p.o_scale = c.scale(l.bn); p.o_shift = c.shift(l.bn); p.o_cmask = l.bnC - 1; }
+  if (in_bncopy != nullptr) { p.A = in_bncopy; in_bn = -1; }   // the producer already applied its BatchNorm
   if (in_bn >= 0) { p.a_scale = c.scale(in_bn); p.a_shift = c.shift(in_bn); p.aff_mask = in_bnC - 1; p.aff_spatial = aff_spatial; }
   p.Nb = c.B; p.Hin = l.Hin; p.Win = l.Hin; p.Cin = l.Cin; p.Hout = l.Hout; p.Wout = l.Hout; p.Cout = l.Cout;
   p.kh = l.k; p.kw = l.k; p.stride = l.stride; p.pb = l.pb; p.mode = mode;
@@ -647,17 +662,18 @@ static int encoder_forward(Ctx& c, const float* x) {
   const VeexNet* n = c.n;
   const Plan& P = c.plan;
   float* ws = c.ws;
-  TRY(veex_conv1_fwd_bf16(x, c.P + n->conv[0].w, c.P + n->conv[0].b, ws + P.act_conv[0], c.scale(n->conv[0].bn),
-                          c.shift(n->conv[0].bn), bfp(c, P.bf_act_conv[0]), c.B, c.st));
+  TRY(veex_conv1_fwd_copies(x, c.P + n->conv[0].w, c.P + n->conv[0].b, ws + P.act_conv[0], c.scale(n->conv[0].bn),
+                            c.shift(n->conv[0].bn), bnp(c, P.bn_conv[0]), bfp(c, P.bf_act_conv[0]), c.B, c.st));
   TRY(fwd_gemm(c, n->conv[1], 0, ws + P.act_conv[0], n->conv[0].bn, 64, 0, ws + P.act_conv[1], 1, packed_w(c, 0, 1),
-               bfp(c, P.bf_act_conv[0]), bfp(c, P.bf_act_conv[1]), packed_wt(c, 0)));
+               bfp(c, P.bf_act_conv[0]), bfp(c, P.bf_act_conv[1]), packed_wt(c, 0), bnp(c, P.bn_conv[0]), bnp(c, P.bn_conv[1])));
   TRY(fwd_gemm(c, n->conv[2], 0, ws + P.act_conv[1], n->conv[1].bn, 128, 0, ws + P.act_conv[2], 1, packed_w(c, 1, 1),
-               bfp(c, P.bf_act_conv[1]), nullptr, packed_wt(c, 1)));
+               bfp(c, P.bf_act_conv[1]), nullptr, packed_wt(c, 1), bnp(c, P.bn_conv[1]), bnp(c, P.bn_conv[2])));
   {  // Dense(6400 -> H1, relu) as a 5x5 VALID conv, split-K over taps/channels
     const ConvLayer& l = n->dense;
     GGParams p; memset(&p, 0, sizeof(p));
     p.A = ws + P.act_conv[2]; p.W = c.P + l.w; p.Out = ws + P.slab;
     p.a_scale = c.scale(n->conv[2].bn); p.a_shift = c.shift(n->conv[2].bn); p.aff_mask = 255;
+    if (const float* y = bnp(c, P.bn_conv[2])) { p.A = y; p.a_scale = p.a_shift = nullptr; p.aff_mask = 0; }
     p.Nb = c.B; p.Hin = 5; p.Win = 5; p.Cin = 256; p.Hout = 1; p.Wout = 1; p.Cout = l.Cout;
     p.kh = 5; p.kw = 5; p.stride = 1; p.pb = 0; p.mode = 0; p.epi = VEEX_EPI_RAW;
     const int chunks = 25 * 16;
@@ -685,14 +701,18 @@ static int decoder_trunk(Ctx& c, const float* z) {
   const VeexNet* n = c.n;
   const Plan& P = c.plan;
   float* ws = c.ws;
-  TRY(fwd_gemm(c, n->ddense, 0, z, -1, 0, 0, ws + P.act_dd, 1, nullptr, nullptr, bfp(c, P.bf_act_dd)));
+  TRY(fwd_gemm(c, n->ddense, 0, z, -1, 0, 0, ws + P.act_dd, 1, nullptr, nullptr, bfp(c, P.bf_act_dd), nullptr, nullptr,
+               bnp(c, P.bn_dd)));
   const float* in = ws + P.act_dd;
+  const float* in_y = bnp(c, P.bn_dd);
   const void* in_bf = bfp(c, P.bf_act_dd);
   int in_bn = n->ddense.bn, in_bnC = 4096, spatial = 1;
   for (int i = 0; i < 5; ++i) {
     void* out_bf = (i < 4) ? bfp(c, P.bf_act_dc[i]) : nullptr;   // deconv5's consumer (deconv6) reads fp32
-    TRY(fwd_gemm(c, n->dc[i], 1, in, in_bn, in_bnC, spatial, ws + P.act_dc[i], 1, packed_w(c, i + 2, 1), in_bf, out_bf));
-    in = ws + P.act_dc[i]; in_bf = out_bf; in_bn = n->dc[i].bn; in_bnC = n->dc[i].Cout; spatial = 0;
+    float* out_y = (i < 4) ? bnp(c, P.bn_dc[i]) : nullptr;       // (and applies BatchNorm 5 itself)
+    TRY(fwd_gemm(c, n->dc[i], 1, in, in_bn, in_bnC, spatial, ws + P.act_dc[i], 1, packed_w(c, i + 2, 1), in_bf, out_bf,
+                 nullptr, in_y, out_y));
+    in = ws + P.act_dc[i]; in_y = out_y; in_bf = out_bf; in_bn = n->dc[i].bn; in_bnC = n->dc[i].Cout; spatial = 0;
   }
   return 0;
 }
@@ -756,6 +776,9 @@ static void deconv_wgrad_desc(Ctx& c, int i, WGParams& w) {
   w.Big = c.ws + P.d_dc[i]; w.Small = (i == 0) ? c.ws + P.act_dd : c.ws + P.act_dc[i - 1];
   w.BigBf = bfp(c, P.bf_d_dc[i]); w.SmallBf = (i == 0) ? bfp(c, P.bf_act_dd) : bfp(c, P.bf_act_dc[i - 1]);
   w.s_scale = c.scale(prod.bn); w.s_shift = c.shift(prod.bn); w.s_aff_mask = prod.bnC - 1; w.s_aff_spatial = (i == 0);
+  if (const float* y = bnp(c, (i == 0) ? P.bn_dd : P.bn_dc[i - 1])) {   // the producer's BatchNorm-applied copy: no affine
+    w.Small = y; w.s_scale = w.s_shift = nullptr; w.s_aff_mask = 0; w.s_aff_spatial = 0;
+  }
 }
 static void deconv_dgrad_desc(Ctx& c, int i, GGParams& p) {
   const VeexNet* n = c.n;
@@ -840,6 +863,7 @@ static int encoder_backward(Ctx& c, const float* x, float* G, int want_param_gra
     WGParams w; wg_desc_conv(n->dense, c.B, w);
     w.Big = ws + P.act_conv[2]; w.Small = ws + P.d_h;
     w.b_scale = c.scale(n->conv[2].bn); w.b_shift = c.shift(n->conv[2].bn); w.b_aff_mask = 255;
+    if (const float* y = bnp(c, P.bn_conv[2])) { w.Big = y; w.b_scale = w.b_shift = nullptr; w.b_aff_mask = 0; }
     TRY(run_wgrad(c, w, G + n->dense.w));
   }
   {  // g3 = d_h . W^T as a plain GEMM over the flattened (h,w,c) vector; epilogue = BN3/ReLU backward
@@ -857,6 +881,7 @@ static int encoder_backward(Ctx& c, const float* x, float* G, int want_param_gra
       w.Big = ws + P.act_conv[i - 1]; w.Small = ws + P.d_conv[i];
       w.BigBf = bfp(c, P.bf_act_conv[i - 1]); w.SmallBf = bfp(c, P.bf_d_conv[i]);
       w.b_scale = c.scale(n->conv[i - 1].bn); w.b_shift = c.shift(n->conv[i - 1].bn); w.b_aff_mask = n->conv[i - 1].Cout - 1;
+      if (const float* y = bnp(c, P.bn_conv[i - 1])) { w.Big = y; w.b_scale = w.b_shift = nullptr; w.b_aff_mask = 0; }
       TRY(run_wgrad(c, w, G + l.w));
     }
     GGParams p; memset(&p, 0, sizeof(p));

@@ -49,7 +49,8 @@ __device__ __forceinline__ void conv1_stage(const float* __restrict__ xsrc, int 
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ out,
                                                         int nunits, const float* __restrict__ bscale,
-                                                        const float* __restrict__ bshift, __bf16* __restrict__ out_bf) {
+                                                        const float* __restrict__ bshift, __bf16* __restrict__ out_bf,
+                                                        float* __restrict__ out_bn) {
   __shared__ __attribute__((aligned(16))) float xs[C1_IROWS * C1_LDW];
   const int cq = threadIdx.x & 15, pg = threadIdx.x >> 4;
   float4 w[9];
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
   for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const float4*>(W + t * NCH + 4 * cq);
   const float4 b4 = *reinterpret_cast<const float4*>(bias + 4 * cq);
   float4 osc = make_float4(1.f, 1.f, 1.f, 1.f), osh = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (out_bf != nullptr) {   // bf16 consumer copy: this layer's BatchNorm applied (what conv2 reads)
+  if (out_bf != nullptr || out_bn != nullptr) {   // consumer copies: this layer's BatchNorm applied (what conv2 reads)
     osc = *reinterpret_cast<const float4*>(bscale + 4 * cq);
     osh = *reinterpret_cast<const float4*>(bshift + 4 * cq);
   }
@@ -90,6 +91,9 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
         h[2] = (__bf16)fmaf(acc.z, osc.z, osh.z); h[3] = (__bf16)fmaf(acc.w, osc.w, osh.w);
         *reinterpret_cast<bf16x4_t*>(out_bf + (pix0 + lp) * NCH + 4 * cq) = h;
       }
+      if (out_bn != nullptr)
+        *reinterpret_cast<float4*>(out_bn + (pix0 + lp) * NCH + 4 * cq) =
+            make_float4(fmaf(acc.x, osc.x, osh.x), fmaf(acc.y, osc.y, osh.y), fmaf(acc.z, osc.z, osh.z), fmaf(acc.w, osc.w, osh.w));
     }
   }
 }
@@ -836,15 +840,22 @@ static inline int grid_for(long long work, int per_block, int cap) {
 extern "C" {
 
 int veex_conv1_fwd(const float* x, const float* W, const float* bias, float* out, int B, hipStream_t st) {
-  return veex_conv1_fwd_bf16(x, W, bias, out, nullptr, nullptr, nullptr, B, st);
+  return veex_conv1_fwd_copies(x, W, bias, out, nullptr, nullptr, nullptr, nullptr, B, st);
 }
 
 int veex_conv1_fwd_bf16(const float* x, const float* W, const float* bias, float* out, const float* bn_scale,
                         const float* bn_shift, void* out_bf16, int B, hipStream_t st) {
-  if (out_bf16 != nullptr && (bn_scale == nullptr || bn_shift == nullptr)) { veex_set_error("conv1_fwd: bf16 copy needs the BatchNorm affine"); return -1; }
+  return veex_conv1_fwd_copies(x, W, bias, out, bn_scale, bn_shift, nullptr, out_bf16, B, st);
+}
+
+int veex_conv1_fwd_copies(const float* x, const float* W, const float* bias, float* out, const float* bn_scale,
+                          const float* bn_shift, float* out_bn, void* out_bf16, int B, hipStream_t st) {
+  if ((out_bf16 != nullptr || out_bn != nullptr) && (bn_scale == nullptr || bn_shift == nullptr)) {
+    veex_set_error("conv1_fwd: a consumer copy needs the BatchNorm affine"); return -1;
+  }
   const int nunits = 2 * B;    // ten output rows of one sample each
   hipLaunchKernelGGL(conv1_fwd_kernel, dim3(grid_for(nunits, 1, 2048)), dim3(256), 0, st, x, W, bias, out, nunits, bn_scale,
-                     bn_shift, reinterpret_cast<__bf16*>(out_bf16));
+                     bn_shift, reinterpret_cast<__bf16*>(out_bf16), out_bn);
   VEEX_CHECK_LAUNCH();
   return 0;
 }

@@ -52,6 +52,9 @@ struct GGParams {
   const float* o_scale;  // EPI_FWD: BatchNorm of THIS layer for OutBf (nullable: plain rounding)
   const float* o_shift;
   int o_cmask;           // o_scale index = col & o_cmask
+  float* OutBn;          // optional (EPI_FWD): fp32 copy o_scale[c]*out + o_shift[c] -- THIS layer's BatchNorm applied once by
+                         // the producer, so that the fp32 GEMMs that consume the activation (next forward, weight gradient)
+                         // stage it without an affine prologue (and zero padding is zero again without a masked shift)
   int row_order;         // lean fp32 kernel: 0 = tile rows run over (n, y, x), 1 = over (y, n, x) -- one image row per tile,
                          // 2 = over (y, x, n) with Nb % tile rows == 0 -- one output pixel per tile, 3 = the same with the
                          // pixels of a phase visited centre-out (longest tiles first)
@@ -131,6 +134,8 @@ int veex_launch_wgrad_v3(const WGParams& p, int bm, int bn, hipStream_t st);
 int veex_launch_wgrad_bf16(const WGParams& p, hipStream_t st);
 extern "C" int veex_conv1_fwd_bf16(const float* x, const float* W, const float* bias, float* out, const float* bn_scale,
                                    const float* bn_shift, void* out_bf16, int B, hipStream_t st);
+extern "C" int veex_conv1_fwd_copies(const float* x, const float* W, const float* bias, float* out, const float* bn_scale,
+                                     const float* bn_shift, float* out_bn, void* out_bf16, int B, hipStream_t st);
 extern "C" int veex_deconv6_bwd_bf16(const float* dlogit, const float* a5, const float* scale, const float* shift,
                                      const float* W6, float* dpre5, void* dpre5_bf16, float* slab, int B, hipStream_t st);
 int veex_pack_weights_bf16_multi(int n, const float* const* src, void* const* dst, const int* taps, const int* rows,

@@ -8,6 +8,7 @@ MI355X_MICROARCH.md); the HBM-bound kernels are priced in bytes against 8 TB/s.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -84,6 +85,9 @@ def gemm_cases(B, bf16=False):
     """Yield (label, macs, launch_fn) for every MFMA launch of one train step at batch B."""
     stream = _lib.current_stream
     keep = []
+    # fp32 engine: producers write a BatchNorm-applied fp32 copy (VeexGemmDesc::out_bn) and consumers read it without an
+    # affine prologue, as the whole-step entry points do (VEEX_BNCOPY=0: consumers apply the affine, as in round 1)
+    bncopy = (not bf16) and os.environ.get("VEEX_BNCOPY", "1") != "0"
 
     def gg(label, macs, mode, A, W, out, N, Hin, Cin, Hout, Cout, k, stride, pb, aff=None, spatial=0, epi=0,
            aux=None, esc=None, wbf=None, osc=None):
@@ -104,8 +108,12 @@ def gemm_cases(B, bf16=False):
             keep.extend([abf, obf]); d.in_bf16, d.out_bf16 = abf.data_ptr(), obf.data_ptr()
             if osc is not None:
                 keep.append(osc); d.out_scale, d.out_shift, d.out_channels = osc[0].data_ptr(), osc[1].data_ptr(), osc[0].numel()
-        if aff is not None:
+        if aff is not None and not (bncopy and epi == 0):
             d.in_scale, d.in_shift, d.affine_channels, d.affine_spatial = aff[0].data_ptr(), aff[1].data_ptr(), aff[0].numel(), spatial
+        if bncopy and epi == 0 and osc is not None and label != "dec.deconv5.fwd":   # deconv6 applies BatchNorm 5 itself
+            obn = torch.empty_like(out)
+            keep.extend([obn, osc]); d.out_bn = obn.data_ptr()
+            d.out_scale, d.out_shift, d.out_channels = osc[0].data_ptr(), osc[1].data_ptr(), osc[0].numel()
         if epi == 0:
             bias = _rand(Cout); keep.append(bias); d.bias = bias.data_ptr(); d.relu = 1
         else:
@@ -128,6 +136,8 @@ def gemm_cases(B, bf16=False):
     def wg(label, macs, big, small, N, Hb, Cb, Hs, Cs, k, stride, pb, aff_small=None, aff_big=None):
         d = WgradDesc()
         d.big, d.small = big.data_ptr(), small.data_ptr()
+        if bncopy:
+            aff_small = aff_big = None
         if aff_small is not None:
             d.small_scale, d.small_shift, d.small_affine_channels = aff_small[0].data_ptr(), aff_small[1].data_ptr(), aff_small[0].numel()
         if aff_big is not None:
@@ -199,6 +209,8 @@ def algorithmic_bytes(label, B, bf16=False):
     e = 2 if bf16 else 4                      # operand element size
     ocopy = 2 if bf16 else 0                  # extra bf16 copy of a result
     if kind == "fwd":
+        if not bf16 and layer != "dec.deconv5" and os.environ.get("VEEX_BNCOPY", "1") != "0":
+            ocopy = 4                         # the BatchNorm-applied fp32 copy the next GEMMs read
         return n_in * e + n_w * e + n_out * (4 + ocopy)
     if kind == "dgrad":                       # reads d(out) and the activation of the layer below, writes d(in)
         aux = 0 if (layer == "dec.deconv1") else n_in * 4
