@@ -1,8 +1,10 @@
 """GPU: the lean fp32 gather kernel against the general one, launch by launch through the operator-level C-ABI
-(veex_gather_gemm), at the full training batch -- where its tiles run over (image row, sample, column), taps that
-are padding for a whole tile are skipped and the blocks are dealt per sample group over the XCDs.  Skipped products
-are exact zeros and the k order is the same, so the outputs must be BIT-identical; the per-tile column partials sit
-in other tiles, so their column totals are compared (fp32 rounding of a different summation order)."""
+(veex_gather_gemm), at the full training batch -- where its tiles run over (image row, sample, column) or hold one
+output pixel each, taps that are padding for a whole tile are skipped and the blocks are dealt per sample group over
+the XCDs.  Skipped products are exact zeros and the k order is the same, so the outputs must be BIT-identical; the
+per-tile column partials sit in other tiles, so their column totals are compared (fp32 rounding of a different
+summation order).  Also: the BatchNorm-applied fp32 copy a producer writes (out_bn) against the affine prologue of
+its consumer.  The library freezes its switches at first use: they are flipped with _lib.setenv."""
 import ctypes as C
 import os
 
@@ -61,11 +63,11 @@ def test_lean_gather_kernel_is_bit_identical_to_the_general_one(case):
         d.out = tmp.data_ptr()
         mt = lib.veex_gather_gemm_m_tiles(C.byref(d))
         assert mt > 0
-    saved = {v: os.environ.get(v) for v in ("VEEX_GGV3", "VEEX_ROWORD")}
+    saved = {v: os.environ.get(v) for v in ("VEEX_GGV3", "VEEX_ROWORD", "VEEX_TILEPERM")}
     res = []
     try:
-        for v3, ro in (("0", "0"), ("1", "0"), ("1", "1")):
-            os.environ["VEEX_GGV3"], os.environ["VEEX_ROWORD"] = v3, ro
+        for v3, ro, perm in (("0", "0", "0"), ("1", "0", "0"), ("1", "1", "0"), ("1", "2", "0"), ("1", "2", "1")):
+            _lib.setenv("VEEX_GGV3", v3); _lib.setenv("VEEX_ROWORD", ro); _lib.setenv("VEEX_TILEPERM", perm)
             out = torch.full((N, Hout, Hout, Cout), 7.0, device="cuda")
             d.out = out.data_ptr()
             part = None
@@ -77,15 +79,93 @@ def test_lean_gather_kernel_is_bit_identical_to_the_general_one(case):
             res.append((out, part))
     finally:
         for v, val in saved.items():
-            if val is None:
-                os.environ.pop(v, None)
-            else:
-                os.environ[v] = val
+            _lib.setenv(v, val)
     ref = res[0][0]
     assert torch.isfinite(ref).all() and float(ref.abs().max()) > 0
     assert torch.equal(ref, res[1][0]), "lean kernel, sample-major tiles"
     assert torch.equal(ref, res[2][0]), "lean kernel, row-major tiles with skipped padding taps"
+    assert torch.equal(ref, res[3][0]), "lean kernel, one output pixel per tile"
+    assert torch.equal(ref, res[4][0]), "lean kernel, one output pixel per tile, centre-out"
     if epi == 1:
         assert torch.equal(res[0][1], res[1][1])
-        ta, tc = res[0][1].view(mt, 3, Cout).sum(0), res[2][1].view(mt, 3, Cout).sum(0)
-        assert float((ta - tc).abs().max()) <= 1e-5 * float(ta.abs().max())
+        ta = res[0][1].view(mt, 3, Cout).sum(0)
+        for r in res[2:]:
+            tc = r[1].view(mt, 3, Cout).sum(0)
+            assert float((ta - tc).abs().max()) <= 1e-5 * float(ta.abs().max())
+
+
+def test_batchnorm_applied_copy_equals_the_consumer_prologue():
+    """VeexGemmDesc::out_bn: the producer's epilogue writes fma(out, scale, shift); a consumer that reads that copy
+    without in_scale / in_shift gives the same bits as one that reads `out` with the affine prologue (padding
+    included: zero stays zero either way), for the gather GEMM and for the weight-gradient GEMM; veex_conv1_fwd_copies
+    writes the same copy for conv1."""
+    import torch
+    from vae_eeg_xai_amd import _lib
+    from vae_eeg_xai_amd._lib import lib, check, GemmDesc, WgradDesc
+    g = torch.Generator(device="cuda").manual_seed(9)
+
+    def R(*shape):
+        return torch.rand(*shape, device="cuda", generator=g) - 0.5
+
+    st = _lib.current_stream
+    N = 128
+    # producer: deconv3-shaped (8 -> 17, 128 -> 128, stride 2, valid); consumer: deconv4-shaped (17 -> 19, 128 -> 64)
+    x, W3, b3 = R(N, 8, 8, 128), R(3, 3, 128, 128) * 0.1, R(128)
+    sc, sh = torch.rand(128, device="cuda", generator=g) + 0.5, R(128)
+    a3, y3 = torch.empty(N, 17, 17, 128, device="cuda"), torch.empty(N, 17, 17, 128, device="cuda")
+    d = GemmDesc()
+    d.inp, d.weight, d.bias, d.out, d.out_bn = x.data_ptr(), W3.data_ptr(), b3.data_ptr(), a3.data_ptr(), y3.data_ptr()
+    d.out_scale, d.out_shift, d.out_channels = sc.data_ptr(), sh.data_ptr(), 128
+    d.N, d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.Cout = N, 8, 8, 128, 17, 17, 128
+    d.kh = d.kw = 3
+    d.stride, d.pad_begin, d.mode, d.epilogue, d.relu, d.nsplit = 2, 0, 1, 0, 1, 1
+    check(lib.veex_gather_gemm(C.byref(d), st()), "producer")
+    torch.cuda.synchronize()
+    assert float(a3.max()) > 0 and float((a3 == 0).float().mean()) > 0.1          # ReLU is active
+    assert torch.equal(y3, torch.addcmul(sh.expand_as(a3), a3, sc.expand_as(a3))) or \
+        float((y3 - (a3 * sc + sh)).abs().max()) <= 1e-6                          # fma vs mul+add: one rounding apart
+    W4, b4 = R(3, 3, 64, 128) * 0.1, R(64)
+    outs = []
+    for src, affine in ((a3, True), (y3, False)):
+        o = torch.empty(N, 19, 19, 64, device="cuda")
+        c = GemmDesc()
+        c.inp, c.weight, c.bias, c.out = src.data_ptr(), W4.data_ptr(), b4.data_ptr(), o.data_ptr()
+        if affine:
+            c.in_scale, c.in_shift, c.affine_channels = sc.data_ptr(), sh.data_ptr(), 128
+        c.N, c.Hin, c.Win, c.Cin, c.Hout, c.Wout, c.Cout = N, 17, 17, 128, 19, 19, 64
+        c.kh = c.kw = 3
+        c.stride, c.pad_begin, c.mode, c.epilogue, c.relu, c.nsplit = 1, 0, 1, 0, 1, 1
+        check(lib.veex_gather_gemm(C.byref(c), st()), "consumer")
+        torch.cuda.synchronize()
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1])
+    # weight gradient of the consumer: small = its input (affine or copy), big = d(pre-activation)
+    dy = R(N, 19, 19, 64)
+    grads = []
+    for src, affine in ((a3, True), (y3, False)):
+        w = WgradDesc()
+        w.big, w.small = dy.data_ptr(), src.data_ptr()
+        if affine:
+            w.small_scale, w.small_shift, w.small_affine_channels = sc.data_ptr(), sh.data_ptr(), 128
+        w.N, w.Hb, w.Wb, w.Cb, w.Hs, w.Ws, w.Cs = N, 19, 19, 64, 17, 17, 128
+        w.kh = w.kw = 3
+        w.stride, w.pad_begin = 1, 0
+        ns, per = C.c_int32(), C.c_int32()
+        check(lib.veex_wgrad_plan(C.byref(w), C.byref(ns), C.byref(per)), "plan")
+        w.nsplit, w.rows_per_split = ns.value, per.value
+        slab = torch.empty(ns.value * 9 * 64 * 128, device="cuda")
+        w.out = slab.data_ptr()
+        check(lib.veex_wgrad_gemm(C.byref(w), st()), "wgrad")
+        torch.cuda.synchronize()
+        grads.append(slab)
+    assert torch.equal(grads[0], grads[1])
+    # conv1: the copy next to the activation
+    xi, W1, b1 = torch.rand(N, 40, 40, device="cuda", generator=g), R(3, 3, 1, 64), R(64)
+    s1, h1 = torch.rand(64, device="cuda", generator=g) + 0.5, R(64)
+    a1, y1, a1b = (torch.empty(N, 20, 20, 64, device="cuda") for _ in range(3))
+    check(lib.veex_conv1_fwd_copies(xi.data_ptr(), W1.data_ptr(), b1.data_ptr(), a1.data_ptr(), s1.data_ptr(), h1.data_ptr(),
+                                    y1.data_ptr(), None, N, st()), "conv1 copies")
+    check(lib.veex_conv1_fwd(xi.data_ptr(), W1.data_ptr(), b1.data_ptr(), a1b.data_ptr(), N, st()), "conv1")
+    torch.cuda.synchronize()
+    assert torch.equal(a1, a1b)
+    assert float((y1 - (a1 * s1 + h1)).abs().max()) <= 1e-6

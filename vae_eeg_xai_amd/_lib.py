@@ -135,8 +135,12 @@ lib = _load()
 
 def setenv(name: str, value) -> None:
     """Flip a tuning switch inside a running process: libveex.so freezes every switch at its
-    first use, so the A/B tools set the variable AND make the library forget its cached values."""
-    os.environ[name] = str(value)
+    first use, so the A/B tools set the variable AND make the library forget its cached values.
+    ``value=None`` unsets it (back to the default)."""
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = str(value)
     lib.veexi_debug_reload_env()
 
 
