@@ -30,4 +30,9 @@ VEEX_DIST_BACKEND=gloo VEEX_DIST_ONE_GPU=1 timeout -k 10 400 python -m torch.dis
 for L in 2 8 16 28 64 128; do
   timeout -k 10 200 python bench.py --batch 1024 --latent $L --steps 30 --warmup 10 --no-cpu-baseline --no-roofline --no-attribution 2>/dev/null >> $O/latent_sweep_b1024.jsonl
 done
+# the bench line over the batch size (fp32 and bf16): how the per-launch floors amortise
+for B in 64 512 2048 4096; do
+  timeout -k 10 200 python bench.py --batch $B --steps 30 --warmup 10 --no-cpu-baseline --no-roofline --no-attribution 2>/dev/null >> $O/bench_batches.jsonl
+  timeout -k 10 200 python bench.py --dtype bf16 --batch $B --steps 30 --warmup 10 --no-cpu-baseline --no-roofline --no-attribution 2>/dev/null >> $O/bench_bf16_batches.jsonl
+done
 echo PROFILES_DONE

@@ -99,15 +99,24 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
   const int Mph = p.Nb * Hp * Wp;
   int m0 = (tile - p.tile_prefix[ph]) * BM;
   if (p.row_order == 3) {
-    // one pixel per tile, pixels visited centre-out in y and in x: the tiles with the most valid taps are dispatched
-    // first and the short border tiles fill the tail of the launch (tile lengths differ 9:1 here)
+    // one pixel per tile, interior pixels (every tap valid) first, in raster order, then the border rows / columns
+    // from the inside out: the longest tiles are dispatched first and the short border tiles fill the tail of the
+    // launch (tile lengths differ 9:1 here), while the raster order of the interior keeps the L2 reuse of a plain sweep
     const int t = tile - p.tile_prefix[ph], G = p.row_tiles;
     int pix, g, yi, xi;
     g3_divmod(t, G, 1.0f / (float)G, pix, g);
     g3_divmod(pix, Wp, 1.0f / (float)Wp, yi, xi);
-    const int cy = (Hp - 1) >> 1, cx = (Wp - 1) >> 1;
-    const int y = (yi & 1) ? cy + ((yi + 1) >> 1) : cy - (yi >> 1);
-    const int x = (xi & 1) ? cx + ((xi + 1) >> 1) : cx - (xi >> 1);
+    const int bl = p.perm_lo, bh = p.perm_hi;
+    auto perm = [bl, bh](int k, int n) {
+      const int ni = n - bl - bh;
+      if (k < ni) return k + bl;
+      int r = k - ni;
+      const int pairs = bl < bh ? bl : bh;
+      if (r < 2 * pairs) return (r & 1) ? n - bh + (r >> 1) : bl - 1 - (r >> 1);
+      r -= 2 * pairs;
+      return (bl > bh) ? bl - 1 - pairs - r : n - bh + pairs + r;
+    };
+    const int y = perm(yi, Hp), x = perm(xi, Wp);
     m0 = __builtin_amdgcn_readfirstlane(((y * Wp + x) * G + g) * BM);
   }
   const int n0 = bnt * BN;
@@ -484,9 +493,17 @@ int veex_launch_gather_gemm_v3(GGParams& p, int mtiles, hipStream_t st) {
   // every row of the tile then has the same valid taps, vertically AND horizontally, and the tile executes exactly
   // the in-bounds taps (deconv4 forward: 2 601 tap-pixels instead of the 2 907 that vertical skipping leaves)
   if (p.row_order == 1 && ro == 2 && p.Nb % bm == 0 && mtiles % (p.Nb / bm) == 0) {
-    // centre-out only for one-phase launches (A/B at batch 512: -2...-6 % there; the 4-phase launches, whose phases
-    // already run longest first, lose locality: +2...+7 %)
-    p.row_order = (p.nphase == 1 && veex_env_int("VEEX_TILEPERM", 1)) ? 3 : 2;
+    // interior-first pixel order for one-phase launches (the 4-phase launches already run their longest phase first).
+    // Border widths = output rows / columns with fewer than kh valid taps, low and high side (square maps).
+    p.row_order = 2;
+    if (p.nphase == 1 && veex_env_int("VEEX_TILEPERM", 1)) {
+      int lo, hi;
+      if (p.mode == 1) { lo = p.kh - 1 - p.pb; hi = p.Hout - p.Hin + p.pb; }                       // stride 1 here
+      else { lo = (p.pb + p.stride - 1) / p.stride; hi = p.Hout - 1 - (p.Hin - p.kh + p.pb) / p.stride; }
+      if (lo >= 0 && hi >= 0 && lo + hi < p.Hout && lo + hi < p.Wout && p.Hout == p.Wout && p.Hin == p.Win && lo + hi > 0) {
+        p.row_order = 3; p.perm_lo = lo; p.perm_hi = hi;
+      }
+    }
     p.row_tiles = p.Nb / bm;
     if (xr < 0) {
       p.remap = 0;

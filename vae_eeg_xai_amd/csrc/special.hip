@@ -930,6 +930,10 @@ int veex_bnrelu_bwd_rows(const float* g, const float* aux, const float* e_scale,
     veex_set_error("bnrelu_bwd_rows: e_channels must be a power of two");
     return -1;
   }
+  if (R < 1 || C < 1 || veex_bnrelu_bwd_rows_chunks(R) > 65535) {
+    veex_set_error("bnrelu_bwd_rows: %d rows x %d columns (at most %d rows per call: split larger inputs)", R, C, 65535 * BRB_ROWS);
+    return -1;
+  }
   const int cmask = (e_scale != nullptr) ? e_channels - 1 : 0;
   hipLaunchKernelGGL(bnrelu_bwd_rows_kernel, dim3((C + 255) / 256, veex_bnrelu_bwd_rows_chunks(R)), dim3(256), 0, st, g, aux,
                      e_scale, out, partials, R, C, cmask);

@@ -57,7 +57,8 @@ struct GGParams {
                          // stage it without an affine prologue (and zero padding is zero again without a masked shift)
   int row_order;         // lean fp32 kernel: 0 = tile rows run over (n, y, x), 1 = over (y, n, x) -- one image row per tile,
                          // 2 = over (y, x, n) with Nb % tile rows == 0 -- one output pixel per tile, 3 = the same with the
-                         // pixels of a phase visited centre-out (longest tiles first)
+                         // interior pixels first in raster order, then the border rows / columns (longest tiles first)
+  int perm_lo, perm_hi;  // row_order 3: output rows / columns at the low / high border that have padded taps
   int row_tiles;         // m tiles per image row (row_order 1, remap 2) / per pixel (row_order 2, 3); with remap == 2 a multiple
                          // of 8: XCD x owns the tiles g % 8 == x of every row / pixel
 };
