@@ -250,7 +250,8 @@ int veex_net_set_compute(VeexNet* net, int compute);
 
 /* Optional second stream (caller-owned, same device): veex_net_train_fwd_bwd then runs every weight-gradient GEMM
  * and its slab reduction there, concurrently with the input-gradient chain on the main stream, and makes the main
- * stream wait for it before returning (fork/join with events the net creates on first use; capturable).
+ * stream wait for it before returning (fork/join with eight events created by THIS call, so the step itself
+ * creates nothing and can run under stream capture).
  * NULL (default) = everything on the one stream passed to the call. */
 int veex_net_set_side_stream(VeexNet* net, veexStream_t side);
 

@@ -175,7 +175,7 @@ struct VeexNet {
   double batch_div = 0.0;       // divisor of the batch-mean loss; 0 = the batch of the call (veex_net_set_batch_divisor)
   hipStream_t side = nullptr;   // optional caller-owned second stream for the weight-gradient GEMMs
   mutable hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  mutable int ev_next = 0;      // fork / join events (host objects, created on first use)
+  mutable int ev_next = 0;      // fork / join events (host objects, created by veex_net_set_side_stream)
   long long n_params, n_state;
   int n_bn;                     // total BatchNorm channels
   long long gamma_off, beta_off;  // trainable buffer
@@ -297,6 +297,17 @@ extern "C" void veex_net_destroy(VeexNet* n) {
 }
 extern "C" int veex_net_set_side_stream(VeexNet* n, veexStream_t side) {
   if (n == nullptr) { veex_set_error("set_side_stream: null net"); return VEEX_EINVAL; }
+  // the fork / join events are created HERE, not on first use inside veex_net_train_fwd_bwd: that call may run under
+  // stream capture, and it creates nothing (host objects included)
+  if (side != nullptr) {
+    for (int i = 0; i < 8; ++i) {
+      if (n->ev[i] == nullptr && hipEventCreateWithFlags(&n->ev[i], hipEventDisableTiming) != hipSuccess) {
+        n->ev[i] = nullptr;
+        veex_set_error("set_side_stream: cannot create the fork / join events");
+        return VEEX_ELAUNCH;
+      }
+    }
+  }
   n->side = side;
   return 0;
 }
@@ -727,8 +738,7 @@ static int deconv6_forward(Ctx& c, const float* target, float* logits, float* re
 static hipEvent_t next_event(const VeexNet* n) {
   const int i = n->ev_next;
   n->ev_next = (i + 1) & 7;
-  if (n->ev[i] == nullptr && hipEventCreateWithFlags(&n->ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-  return n->ev[i];
+  return n->ev[i];   // created by veex_net_set_side_stream
 }
 // side stream waits for everything enqueued on the main stream so far
 static int fork_side(Ctx& c) {
