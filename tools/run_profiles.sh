@@ -35,4 +35,6 @@ for B in 64 512 2048 4096; do
   timeout -k 10 200 python bench.py --batch $B --steps 30 --warmup 10 --no-cpu-baseline --no-roofline --no-attribution 2>/dev/null >> $O/bench_batches.jsonl
   timeout -k 10 200 python bench.py --dtype bf16 --batch $B --steps 30 --warmup 10 --no-cpu-baseline --no-roofline --no-attribution 2>/dev/null >> $O/bench_bf16_batches.jsonl
 done
+# the bf16 layer table again at batch 4096: how far the per-launch floors are from the roof once the launches are 8x longer
+timeout -k 10 200 python -m vae_eeg_xai_amd.roofline 4096 bf16 > $O/layer_table_bf16_b4096.txt 2>/dev/null
 echo PROFILES_DONE

@@ -12,7 +12,7 @@ os.makedirs(dst, exist_ok=True)
 shutil.copy(f"{src}/bench.json", f"{dst}/{R}_bench.json")
 shutil.copy(f"{src}/layer_table.txt", f"{dst}/{R}_layer_table.txt")
 for extra in ("bench_bf16.json", "layer_table_bf16.txt", "hbm_table.txt", "dp2_rehearsal.json", "latent_sweep_b1024.jsonl",
-              "bench_batches.jsonl", "bench_bf16_batches.jsonl"):
+              "bench_batches.jsonl", "bench_bf16_batches.jsonl", "layer_table_bf16_b4096.txt"):
     if os.path.exists(f"{src}/{extra}"):
         if extra.startswith(("dp2_", "latent_sweep", "bench_batches", "bench_bf16_batches")):   # one JSON line per run; drop what gloo / the launcher printed beside it
             open(f"{dst}/{R}_{extra}", "w").writelines(l for l in open(f"{src}/{extra}") if l.startswith("{"))

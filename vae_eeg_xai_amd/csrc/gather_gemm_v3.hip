@@ -97,27 +97,34 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
   const int ostep = (p.nphase == 4) ? 2 : 1;
   const int oy0 = p.o0[py], ox0 = p.o0[px];
   const int Mph = p.Nb * Hp * Wp;
-  int m0 = (tile - p.tile_prefix[ph]) * BM;
-  if (p.row_order == 3) {
-    // one pixel per tile, interior pixels (every tap valid) first, in raster order, then the border rows / columns
-    // from the inside out: the longest tiles are dispatched first and the short border tiles fill the tail of the
-    // launch (tile lengths differ 9:1 here), while the raster order of the interior keeps the L2 reuse of a plain sweep
+  const int m0 = (tile - p.tile_prefix[ph]) * BM;
+  // row_order >= 2: the tile is ONE output pixel (uy, ux in phase coordinates) of sample group ug -- wave-uniform, so
+  // everything that depends on the pixel alone (tap validity, input / output pixel offsets) is scalar arithmetic
+  int uy = 0, ux = 0, ug = 0;
+  if (p.row_order >= 2) {
     const int t = tile - p.tile_prefix[ph], G = p.row_tiles;
     int pix, g, yi, xi;
     g3_divmod(t, G, 1.0f / (float)G, pix, g);
     g3_divmod(pix, Wp, 1.0f / (float)Wp, yi, xi);
-    const int bl = p.perm_lo, bh = p.perm_hi;
-    auto perm = [bl, bh](int k, int n) {
-      const int ni = n - bl - bh;
-      if (k < ni) return k + bl;
-      int r = k - ni;
-      const int pairs = bl < bh ? bl : bh;
-      if (r < 2 * pairs) return (r & 1) ? n - bh + (r >> 1) : bl - 1 - (r >> 1);
-      r -= 2 * pairs;
-      return (bl > bh) ? bl - 1 - pairs - r : n - bh + pairs + r;
-    };
-    const int y = perm(yi, Hp), x = perm(xi, Wp);
-    m0 = __builtin_amdgcn_readfirstlane(((y * Wp + x) * G + g) * BM);
+    if (p.row_order == 3) {
+      // interior pixels (every tap valid) first, in raster order, then the border rows / columns from the inside out:
+      // the longest tiles are dispatched first and the short border tiles fill the tail of the launch (tile lengths
+      // differ 9:1 here), while the raster order of the interior keeps the L2 reuse of a plain sweep
+      const int bl = p.perm_lo, bh = p.perm_hi;
+      auto perm = [bl, bh](int k, int n) {
+        const int ni = n - bl - bh;
+        if (k < ni) return k + bl;
+        int r = k - ni;
+        const int pairs = bl < bh ? bl : bh;
+        if (r < 2 * pairs) return (r & 1) ? n - bh + (r >> 1) : bl - 1 - (r >> 1);
+        r -= 2 * pairs;
+        return (bl > bh) ? bl - 1 - pairs - r : n - bh + pairs + r;
+      };
+      yi = perm(yi, Hp); xi = perm(xi, Wp);
+    }
+    uy = __builtin_amdgcn_readfirstlane(yi);
+    ux = __builtin_amdgcn_readfirstlane(xi);
+    ug = __builtin_amdgcn_readfirstlane(g);
   }
   const int n0 = bnt * BN;
 
@@ -166,7 +173,39 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
   // ---- A loader: row tid/4, k-quad tid%4 ----
   const int q = tid & 3, lr = tid >> 2;
   unsigned a_voff = 0u, a_voff2 = 0u, a_inv = 0xFFFFFFFFu;   // a_inv bit t set <=> tap t must read zeros
-  {
+  unsigned umk = 0u;                                          // row_order >= 2: the tile's valid taps (scalar)
+  if (p.row_order >= 2) {
+    // one pixel per tile (Nb % BM == 0: every row is a sample): pixel geometry and tap validity in scalar registers,
+    // per lane only the sample's base offset -- no divisions, no per-lane mask loops, no LDS atomics
+    const int oy = ostep * uy + oy0, ox = ostep * ux + ox0;
+    int by, bx;
+    if (MODE1) { by = (oy + p.pb - kys) >> (p.stride - 1); bx = (ox + p.pb - kxs) >> (p.stride - 1); }
+    else       { by = p.stride * oy - p.pb; bx = p.stride * ox - p.pb; }
+    unsigned xb = 0u;
+    for (int ib = 0; ib < nkx; ++ib) {
+      const int ix = MODE1 ? bx - ib : bx + ib;
+      bool ok = ix >= 0 && ix < p.Win;
+      if (MODE1) ok = ok && (ox + p.pb - (kxs + kstep * ib)) >= 0;
+      if (ok) xb |= 1u << ib;
+    }
+    for (int ia = 0; ia < nky; ++ia) {
+      const int iy = MODE1 ? by - ia : by + ia;
+      bool ok = iy >= 0 && iy < p.Hin;
+      if (MODE1) ok = ok && (oy + p.pb - (kys + kstep * ia)) >= 0;
+      if (ok) umk |= xb << (ia * nkx);
+    }
+    const int pix_in = (MODE1 ? (by * p.Win + bx) : ((by + p.pb) * p.Win + bx + p.pb)) * p.Cin * 4;   // scalar
+    const int pix_out = (oy * p.Wout + ox) * p.Cout * 4;
+    const int n = ug * BM + lr;
+    unsigned out_off = 0x80000000u;
+    if (hasA) {
+      out_off = (unsigned)(n * (p.Hout * p.Wout * p.Cout * 4) + pix_out);
+      a_voff2 = (unsigned)(pix_in + 16 * q);
+      a_voff = (unsigned)(n * (p.Hin * p.Win * p.Cin * 4)) + a_voff2;
+      a_inv = ~umk;
+    }
+    if (q == 0 && hasA) s_offb[lr] = out_off;
+  } else {
     const int m = m0 + lr;
     unsigned out_off = 0x80000000u;   // + any column offset stays out of range: the store is dropped
     if (m < Mph && hasA) {
@@ -201,11 +240,16 @@ __global__ __launch_bounds__(64 * NWM * NWN) __attribute__((amdgpu_waves_per_eu(
     if (q == 0 && hasA) s_offb[lr] = out_off;   // the epilogue's output row byte offsets (read after the K loop's barriers)
   }
   // valid-tap set of the tile: split-K launches keep every tap (their chunk ranges are planned on the host)
-  __syncthreads();
-  if (q == 0 && ~a_inv != 0u) atomicOr(s_tmk, ~a_inv);
-  __syncthreads();
   const unsigned all_taps = (ntaps >= 32) ? 0xFFFFFFFFu : ((1u << ntaps) - 1u);
-  const unsigned tile_mk = (p.nsplit > 1) ? all_taps : (unsigned)__builtin_amdgcn_readfirstlane((int)(*s_tmk & all_taps));
+  unsigned tile_mk;
+  if (p.row_order >= 2) {
+    tile_mk = (unsigned)__builtin_amdgcn_readfirstlane((int)(umk & all_taps));
+  } else {
+    __syncthreads();
+    if (q == 0 && ~a_inv != 0u) atomicOr(s_tmk, ~a_inv);
+    __syncthreads();
+    tile_mk = (p.nsplit > 1) ? all_taps : (unsigned)__builtin_amdgcn_readfirstlane((int)(*s_tmk & all_taps));
+  }
   const int nvalid = __builtin_popcount(tile_mk);
   // ---- B loader ----
   unsigned b_voff;
