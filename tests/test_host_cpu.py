@@ -117,3 +117,29 @@ def test_ragged_shards_with_the_global_divisor_sum_to_the_global_mean():
         for k in names:
             assert np.abs(acc[k] / world - gf[k]).max() <= 1e-12 * max(1.0, np.abs(gf[k]).max()), (world, k)
         assert abs(loss / world - cf["total"]) < 1e-10 * abs(cf["total"])
+
+
+def test_layer_op_geometry_is_the_oracles_and_fake_shapes_trace():
+    """torch.ops.veex.conv2d / conv_transpose2d: the Keras 'same' / 'valid' arithmetic of ops.py equals the oracle's
+    for every layer of the model, and the ops trace under FakeTensorMode (register_fake) without a GPU."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from oracle import vae_oracle as vo
+    from vae_eeg_xai_amd import ops
+    for n_in, k, s, pad in ((40, 3, 2, "same"), (20, 3, 2, "same"), (10, 3, 2, "same"), (7, 3, 1, "valid"), (9, 5, 2, "valid")):
+        if pad == "same":
+            out, pb, _ = vo.same_pad(n_in, k, s)
+        else:
+            out, pb = (n_in - k) // s + 1, 0
+        assert ops.conv_geometry(n_in, k, s, pad) == (out, pb)
+    for n_in, k, s, pad in ((4, 3, 2, "same"), (8, 3, 1, "same"), (8, 3, 2, "valid"), (17, 3, 1, "valid"), (19, 3, 2, "valid"),
+                            (39, 2, 1, "valid")):
+        assert ops.deconv_geometry(n_in, k, s, pad) == vo.deconv_geometry(n_in, k, s, pad)[:2]
+    with FakeTensorMode():
+        x = torch.empty(4, 20, 20, 64, device="cuda")
+        y = torch.ops.veex.conv2d(x, torch.empty(3, 3, 64, 128, device="cuda"), torch.empty(128, device="cuda"), 2, "same", True)
+        assert tuple(y.shape) == (4, 10, 10, 128)
+        z = torch.ops.veex.conv_transpose2d(y, torch.empty(3, 3, 64, 128, device="cuda"), torch.empty(64, device="cuda"), 2, "valid", False)
+        assert tuple(z.shape) == (4, 21, 21, 64)
+        dx, dw, db = torch.ops.veex.conv2d_bwd(y, x, torch.empty(3, 3, 64, 128, device="cuda"), y, 2, "same", True)
+        assert tuple(dx.shape) == (4, 20, 20, 64) and tuple(dw.shape) == (3, 3, 64, 128) and tuple(db.shape) == (128,)
