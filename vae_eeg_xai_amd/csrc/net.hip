@@ -176,6 +176,11 @@ struct VeexNet {
   hipStream_t side = nullptr;   // optional caller-owned second stream for the weight-gradient GEMMs
   mutable hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   mutable int ev_next = 0;      // fork / join events (host objects, created by veex_net_set_side_stream)
+  // timing probe (bench.py's roofline object): two timing events recorded around ONE forward launch of the next
+  // whole-step call, on the launch stream (veexi_debug_probe_arm / veexi_debug_probe_ms)
+  mutable hipEvent_t probe_ev[2] = {nullptr, nullptr};
+  mutable std::string probe_layer;
+  mutable int probe_state = 0;  // 0 off, 1 armed, 2 recorded
   long long n_params, n_state;
   int n_bn;                     // total BatchNorm channels
   long long gamma_off, beta_off;  // trainable buffer
@@ -293,7 +298,28 @@ extern "C" VeexNet* veex_net_create(int L, int variant) {
 extern "C" void veex_net_destroy(VeexNet* n) {
   if (n == nullptr) return;
   for (int i = 0; i < 8; ++i) if (n->ev[i] != nullptr) (void)hipEventDestroy(n->ev[i]);
+  for (int i = 0; i < 2; ++i) if (n->probe_ev[i] != nullptr) (void)hipEventDestroy(n->probe_ev[i]);
   delete n;
+}
+// Measurement aid, not part of the product API: time ONE forward launch (layer = "enc.conv2" ... "dec.deconv5") inside
+// the next veex_net_train_fwd_bwd / veex_net_forward call with HIP events on the stream the kernel is launched on.
+extern "C" int veexi_debug_probe_arm(VeexNet* n, const char* layer) {
+  if (n == nullptr || layer == nullptr) { veex_set_error("probe_arm: null argument"); return VEEX_EINVAL; }
+  for (int i = 0; i < 2; ++i)
+    if (n->probe_ev[i] == nullptr && hipEventCreate(&n->probe_ev[i]) != hipSuccess) {
+      n->probe_ev[i] = nullptr; veex_set_error("probe_arm: cannot create a timing event"); return VEEX_ELAUNCH;
+    }
+  n->probe_layer = layer;
+  n->probe_state = 1;
+  return 0;
+}
+extern "C" int veexi_debug_probe_ms(VeexNet* n, float* ms) {
+  if (n == nullptr || ms == nullptr) { veex_set_error("probe_ms: null argument"); return VEEX_EINVAL; }
+  if (n->probe_state != 2) { veex_set_error("probe_ms: the armed layer was not launched"); n->probe_state = 0; return VEEX_EINVAL; }
+  n->probe_state = 0;
+  if (hipEventSynchronize(n->probe_ev[1]) != hipSuccess ||
+      hipEventElapsedTime(ms, n->probe_ev[0], n->probe_ev[1]) != hipSuccess) { veex_set_error("probe_ms: event query failed"); return VEEX_ELAUNCH; }
+  return 0;
 }
 extern "C" int veex_net_set_side_stream(VeexNet* n, veexStream_t side) {
   if (n == nullptr) { veex_set_error("set_side_stream: null net"); return VEEX_EINVAL; }
@@ -666,7 +692,14 @@ static int fwd_gemm(Ctx& c, const ConvLayer& l, int mode, const float* in, int i
   p.Nb = c.B; p.Hin = l.Hin; p.Win = l.Hin; p.Cin = l.Cin; p.Hout = l.Hout; p.Wout = l.Hout; p.Cout = l.Cout;
   p.kh = l.k; p.kw = l.k; p.stride = l.stride; p.pb = l.pb; p.mode = mode;
   p.epi = VEEX_EPI_FWD; p.relu = relu; p.nsplit = 1;
-  return veex_launch_gather_gemm(p, c.st);
+  const bool probe = c.n->probe_state == 1 && c.n->probe_layer == l.name;
+  if (probe && hipEventRecord(c.n->probe_ev[0], c.st) != hipSuccess) { veex_set_error("probe: event record failed"); return VEEX_ELAUNCH; }
+  const int rc = veex_launch_gather_gemm(p, c.st);
+  if (probe) {
+    if (hipEventRecord(c.n->probe_ev[1], c.st) != hipSuccess) { veex_set_error("probe: event record failed"); return VEEX_ELAUNCH; }
+    c.n->probe_state = 2;
+  }
+  return rc;
 }
 
 static int encoder_forward(Ctx& c, const float* x) {
