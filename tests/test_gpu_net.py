@@ -284,3 +284,30 @@ def test_side_stream_overlap_is_bit_identical_and_graph_capturable():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(net.grads, res[0])
+
+
+def test_timing_probe_times_the_armed_forward_launch():
+    """veexi_debug_probe_*: the measurement aid behind bench.py's roofline object -- HIP events around one forward
+    launch inside a whole-step call.  An armed layer gives a plausible duration; a layer that is never launched
+    is reported as such; results of the step are unaffected."""
+    import ctypes as C
+    import torch
+    from vae_eeg_xai_amd._lib import lib
+    from vae_eeg_xai_amd.net import Net
+    lib.veexi_debug_probe_arm.argtypes = [C.c_void_p, C.c_char_p]
+    lib.veexi_debug_probe_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    net = Net(28, "vae")
+    net.init_weights(seed=5)
+    x = torch.rand(64, 40, 40, 1, device="cuda")
+    ref = net.train_fwd_bwd(x, None, first_sample=0).clone()
+    g_ref = net.grads.clone()
+    ms = C.c_float(-1.0)
+    assert lib.veexi_debug_probe_arm(net._h, b"dec.deconv4") == 0
+    got = net.train_fwd_bwd(x, None, first_sample=0).clone()
+    assert lib.veexi_debug_probe_ms(net._h, C.byref(ms)) == 0
+    assert 0.001 < ms.value < 5.0, ms.value
+    assert torch.equal(ref, got) and torch.equal(g_ref, net.grads)
+    assert lib.veexi_debug_probe_arm(net._h, b"no.such.layer") == 0
+    net.train_fwd_bwd(x, None, first_sample=0)
+    assert lib.veexi_debug_probe_ms(net._h, C.byref(ms)) != 0
+    assert b"not launched" in lib.veex_last_error()
