@@ -393,7 +393,9 @@ static SplitPlan wgrad_split(const WGParams& pin) {
   // Blocks per launch the row split aims at: what fits on the chip at once (3 per CU), equally long, so the launch
   // lasts as long as the fullest CU -- never exceed the target (774 blocks = a 4th block on six CUs = +33 %).
   // (the bf16 copy kernel holds 72 KB of LDS: 2 blocks per CU)
-  const int target = veex_env_int("VEEX_WG_BLOCKS", (pin.bf16 == 2) ? 512 : 768);
+  // (bf16 copy kernel, 72 KB of LDS: ONE block per CU measured best inside the step -- 1.209 -> 1.176 ms at batch 512
+  //  against two per CU, -0.8 % at batch 2 048: half the slab bytes, and the input-gradient launches keep the other slot)
+  const int target = veex_env_int("VEEX_WG_BLOCKS", (pin.bf16 == 2) ? 256 : 768);
   int ns = veex_env_int("VEEX_WG_FLOOR", 1) ? target / tiles : (target + tiles - 1) / tiles;
   const int maxs = (chunks / 4 > 0) ? chunks / 4 : 1;
   if (ns > maxs) ns = maxs;
