@@ -94,3 +94,28 @@ def test_two_rank_fit_reproduces_the_one_process_fit(tmp_path, lr):
         if k.startswith("w."):
             d = np.abs(dp[k] - one[k]).max()
             assert d <= 0.5 * steps * lr + 1e-6 * np.abs(one[k]).max() * (lr > 0), (k, d)
+
+
+def test_rccl_backend_single_rank_fit_equals_the_plain_fit(tmp_path):
+    """The RCCL code path itself (backend "nccl": device tensors straight into the collectives, no host staging) on the
+    one GPU of the box: a process group of ONE rank runs the data-parallel `VAE.fit` -- communicator set-up, the
+    all-reduce of the flat gradient buffer, the seed broadcast and the metrics all-reduce all execute on RCCL -- and
+    must reproduce the plain single-process fit (world = 1: same shards, same divisor)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dp_worker
+    n, batch, epochs, L, seed, n_val, lr = 70, 32, 2, 8, 9, 11, 1e-4
+    out = os.path.join(tmp_path, "rccl1.npz")
+    env = dict(os.environ, VEEX_DIST_BACKEND="nccl", MASTER_ADDR="127.0.0.1")
+    port = 29700 + os.getpid() % 1000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dp_worker.py"), out,
+           *map(str, (n, batch, epochs, L, seed, n_val, lr))]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    dp = np.load(out)
+    one = dp_worker.run_fit(n, batch, epochs, L, seed, n_val, lr)
+    for k in one:
+        if k.startswith("h."):
+            assert np.allclose(dp[k], one[k], rtol=1e-6, atol=0), (k, dp[k], one[k])
+        elif k.startswith("w."):
+            assert np.abs(dp[k] - one[k]).max() <= 1e-6 * max(np.abs(one[k]).max(), 1e-3), k
