@@ -15,7 +15,7 @@ CSRC = os.path.join(ROOT, "vae_eeg_xai_amd", "csrc")
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 # file -> kernels that may keep their (known, cold: prologue of the spatial-affine variants) waterfall loops
-HOT = {"gather_gemm_v3.hip": (), "gather_gemm_bf16.hip": (), "wgrad_gemm_bf16.hip": (),
+HOT = {"gather_gemm_v3.hip": (), "gather_gemm_v4.hip": (), "gather_gemm_bf16.hip": (), "wgrad_gemm_bf16.hip": (),
        "wgrad_gemm_v3.hip": ("ELb0ELi2E",)}
 
 

@@ -169,3 +169,85 @@ def test_batchnorm_applied_copy_equals_the_consumer_prologue():
     torch.cuda.synchronize()
     assert torch.equal(a1, a1b)
     assert float((y1 - (a1 * s1 + h1)).abs().max()) <= 1e-6
+
+
+SMALL = [  # name, mode, N, Hin, Cin, Hout, Cout, k, stride, pad_begin, epilogue   (few-tile launches: the 32x32 split-K kernel)
+    ("deconv4 fwd", 1, 64, 17, 128, 19, 64, 3, 1, 0, 0),
+    ("deconv2 fwd", 1, 5, 8, 256, 8, 128, 3, 1, 1, 0),
+    ("deconv2 dgrad", 0, 64, 8, 128, 8, 256, 3, 1, 1, 1),
+    ("conv2 fwd", 0, 33, 20, 64, 10, 128, 3, 2, 0, 0),
+    ("deconv5 fwd (4 phases)", 1, 3, 19, 64, 39, 64, 3, 2, 0, 0),
+    ("conv3 dgrad (4 phases)", 1, 17, 5, 256, 10, 128, 3, 2, 0, 1),
+    ("deconv1 dgrad", 0, 64, 8, 256, 4, 256, 3, 2, 0, 1),
+    ("one row", 1, 1, 4, 256, 8, 256, 3, 2, 0, 0),
+]
+
+
+@pytest.mark.parametrize("case", SMALL, ids=[c[0] for c in SMALL])
+def test_small_launch_kernel_matches_the_64x64_kernel(case):
+    """gather_gemm_v4 (32x32 tiles, K split over the four waves of a block, taken for launches of few tiles) against
+    the lean 64x64 kernel on the same operands: outputs, the BatchNorm-applied copy and the column totals of the
+    backward epilogue agree to fp32 rounding of a different summation order (1e-5 relative to max-abs; measured ~1e-6)."""
+    import torch
+    from vae_eeg_xai_amd import _lib
+    from vae_eeg_xai_amd._lib import lib, check, GemmDesc
+    name, mode, N, Hin, Cin, Hout, Cout, k, s, pb, epi = case
+    g = torch.Generator(device="cuda").manual_seed(11)
+
+    def R(*shape):
+        return torch.rand(*shape, device="cuda", generator=g) - 0.5
+
+    x = R(N, Hin, Hin, Cin)
+    W = R(k, k, Cin, Cout) if mode == 0 else R(k, k, Cout, Cin)
+    bias = R(Cout)
+    osc, osh = torch.rand(Cout, device="cuda", generator=g) + 0.5, R(Cout)
+    keep = [x, W, bias, osc, osh]
+    d = GemmDesc()
+    d.inp, d.weight, d.bias = x.data_ptr(), W.data_ptr(), bias.data_ptr()
+    if mode == 0:
+        wt = torch.empty(W.numel(), device="cuda")
+        check(lib.veex_transpose_weights_f32(W.data_ptr(), wt.data_ptr(), k * k, Cin, Cout, _lib.current_stream()), "transpose")
+        keep.append(wt)
+        d.weight_t = wt.data_ptr()
+    d.N, d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.Cout = N, Hin, Hin, Cin, Hout, Hout, Cout
+    d.kh = d.kw = k
+    d.stride, d.pad_begin, d.mode = s, pb, mode
+    d.epilogue, d.relu, d.nsplit = epi, 1, 1
+    if epi == 1:
+        aux, esc = R(N, Hout, Hout, Cout), torch.rand(Cout, device="cuda", generator=g) + 0.5
+        keep += [aux, esc]
+        d.aux, d.e_scale, d.e_channels = aux.data_ptr(), esc.data_ptr(), Cout
+    else:
+        d.out_scale, d.out_shift, d.out_channels = osc.data_ptr(), osh.data_ptr(), Cout
+    saved = os.environ.get("VEEX_GGV4")
+    res = []
+    try:
+        for v4 in ("0", "1"):
+            _lib.setenv("VEEX_GGV4", v4)
+            out = torch.full((N, Hout, Hout, Cout), 7.0, device="cuda")
+            obn = torch.full((N, Hout, Hout, Cout), 7.0, device="cuda")
+            d.out = out.data_ptr()
+            part, mt = None, 0
+            if epi == 1:
+                mt = lib.veex_gather_gemm_m_tiles(C.byref(d))
+                assert mt > 0
+                part = torch.zeros(mt * 3 * Cout, device="cuda")
+                d.partials = part.data_ptr()
+            else:
+                d.out_bn = obn.data_ptr()
+            check(lib.veex_gather_gemm(C.byref(d), _lib.current_stream()), name)
+            torch.cuda.synchronize()
+            res.append((out, obn, part, mt))
+    finally:
+        _lib.setenv("VEEX_GGV4", saved)
+    (o0, b0, p0, m0), (o1, b1, p1, m1) = res
+    assert torch.isfinite(o0).all() and float(o0.abs().max()) > 0
+    scale = float(o0.abs().max())
+    assert float((o0 - o1).abs().max()) <= 1e-5 * scale
+    if epi == 0:
+        assert float((b0 - b1).abs().max()) <= 1e-5 * float(b0.abs().max())
+        assert not torch.equal(o0, torch.full_like(o0, 7.0))
+    else:
+        assert m1 >= m0                                    # 32-row tiles: at least as many partial rows
+        t0, t1 = p0.view(m0, 3, Cout).sum(0), p1.view(m1, 3, Cout).sum(0)
+        assert float((t0 - t1).abs().max()) <= 1e-5 * float(t0.abs().max())

@@ -552,6 +552,7 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
 static bool gg_fast_ok_fwd(const GGParams& p);
 int veex_gg_bm(const GGParams& p) {
   const long long M = (long long)p.Nb * p.Hout * p.Wout;
+  if (veex_gg_v4_ok(p)) return 32;   // small launches: 32x32 tiles, K split over the waves of a block (gather_gemm_v4.hip)
   if (M < 4096) return 64;
   const int force = veex_env_int("VEEX_BM", 0);
   if (force == 64 || force == 128) return force;
@@ -729,6 +730,7 @@ int veex_launch_gather_gemm(const GGParams& pin, hipStream_t st) {
   const bool fast = gg_fast_ok(p);
   if (gg_bf16_dispatch(p, fast)) return veex_launch_gather_gemm_bf16(p, mtiles, st);
   if (p.Out == nullptr) { veex_set_error("gather_gemm: null output (only the bf16 engine can write the bf16 copy alone)"); return -1; }
+  if (bm == 32) return veex_launch_gather_gemm_v4(p, mtiles, st);
   if (fast && veex_env_int("VEEX_GGV3", 1) && veex_gg_v3_ok(p) && bm == veex_gg_v3_bm(p)) return veex_launch_gather_gemm_v3(p, mtiles, st);
   if (bm == 128 && bn == 128 && fast) return gg_launch_cfg<128, 128>(p, mtiles, true, st);
   if (bm == 128 && bn == 64 && fast) return gg_launch_cfg<128, 64>(p, mtiles, true, st);

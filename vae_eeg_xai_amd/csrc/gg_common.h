@@ -246,5 +246,7 @@ int veex_launch_gather_gemm_bf16_v3(GGParams& p, int mtiles, int bm, hipStream_t
 int veex_gg_v3_ok(const GGParams& p);                                          // gather_gemm_v3.hip
 int veex_launch_gather_gemm_v3(GGParams& p, int mtiles, hipStream_t st);
 int veex_gg_v3_bm(const GGParams& p);                                          // tile rows the lean fp32 kernel uses
+int veex_gg_v4_ok(const GGParams& p);                                          // gather_gemm_v4.hip (small launches)
+int veex_launch_gather_gemm_v4(GGParams& p, int mtiles, hipStream_t st);
 
 #endif

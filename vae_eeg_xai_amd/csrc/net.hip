@@ -466,10 +466,10 @@ static void wg_desc_conv(const ConvLayer& c, int B, WGParams& p, int bf16 = 0) {
   p.R = B * c.Hout * c.Hout; p.M = c.k * c.k * c.Cin;
 }
 
-static long long gg_tiles_for(int B, int Hout, int Cout, int mode, int stride, int pb) {
+static long long gg_tiles_for(int B, int Hout, int Cout, int mode, int stride, int pb, int bm = 64) {
   GGParams p; memset(&p, 0, sizeof(p));
   p.Nb = B; p.Hout = Hout; p.Wout = Hout; p.Cout = Cout; p.mode = mode; p.stride = stride; p.pb = pb;
-  return veex_gg_m_tiles_bm(p, 64);   // 64-row tiles: an upper bound whatever tile the launcher picks
+  return veex_gg_m_tiles_bm(p, bm);   // smallest tile the launcher may pick: an upper bound on the tile count
 }
 
 // the seven MFMA-bound layers that have a bf16 path: 0,1 = enc.conv2/3, 2..6 = dec.deconv1..5
@@ -532,11 +532,11 @@ static void make_plan(const VeexNet* n, int B, Plan& P) {
   // the pass (take_partials): EPI_BWD launches (m_tiles * 3 * Cout), row-chunk launches, the deconv6 backward rows
   auto acc = [](long long& m, long long v) { m += (v + 63) & ~63LL; };
   for (int i = 1; i < 5; ++i)  // dgrad of deconv i+1 produces gradient of deconv i's output
-    acc(part, gg_tiles_for(B, n->dc[i - 1].Hout, n->dc[i - 1].Cout, 0, 1, 0) * 3 * n->dc[i - 1].Cout);
-  acc(part, gg_tiles_for(B, 1, 6400, 1, 1, 0) * 3 * 6400);
-  acc(part, gg_tiles_for(B, 10, 128, 1, 2, 0) * 3 * 128);
-  acc(part, gg_tiles_for(B, 20, 64, 1, 2, 0) * 3 * 64);
-  acc(part, gg_tiles_for(B, 1, H1, 1, 1, 0) * 3 * H1);
+    acc(part, gg_tiles_for(B, n->dc[i - 1].Hout, n->dc[i - 1].Cout, 0, 1, 0, 32) * 3 * n->dc[i - 1].Cout);
+  acc(part, gg_tiles_for(B, 1, 6400, 1, 1, 0, 32) * 3 * 6400);
+  acc(part, gg_tiles_for(B, 10, 128, 1, 2, 0, 32) * 3 * 128);
+  acc(part, gg_tiles_for(B, 20, 64, 1, 2, 0, 32) * 3 * 64);
+  acc(part, gg_tiles_for(B, 1, H1, 1, 1, 0, 32) * 3 * H1);
   acc(part, (long long)veex_bnrelu_bwd_rows_chunks(B) * 3 * 4096);
   acc(part, (long long)veex_bnrelu_bwd_rows_chunks(B) * 3 * (2 * L > H1 ? 2 * L : H1));
   acc(part, (long long)B * 448);

@@ -127,7 +127,7 @@ def gemm_cases(B, bf16=False):
         if epi == 1:
             # sized for the smallest tile (64 rows, 4 phases) so that tile-size switches flipped by
             # environment variables between launches can never overrun it
-            mt = (N * Hout * Hout + 63) // 64 + 4
+            mt = (N * Hout * Hout + 31) // 32 + 4
             assert lib.veex_gather_gemm_m_tiles(C.byref(d)) <= mt
             part = torch.empty(mt * 3 * Cout, device="cuda"); keep.append(part); d.partials = part.data_ptr()
         keep.extend([A, W, out, d])
