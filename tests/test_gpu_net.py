@@ -311,3 +311,24 @@ def test_timing_probe_times_the_armed_forward_launch():
     net.train_fwd_bwd(x, None, first_sample=0)
     assert lib.veexi_debug_probe_ms(net._h, C.byref(ms)) != 0
     assert b"not launched" in lib.veex_last_error()
+
+
+def test_forward_replayed_from_a_hip_graph_is_bit_identical():
+    """Net.forward_graphed: the forward captured once per batch into a HIP graph (the library only enqueues on the
+    caller's stream and creates nothing) and replayed on new inputs gives the eager result bit for bit."""
+    import torch
+    from vae_eeg_xai_amd.net import Net
+    for variant in ("vae", "ae"):
+        net = Net(28, variant)
+        net.init_weights(seed=7)
+        g = torch.Generator(device="cuda").manual_seed(2)
+        for B in (1, 8):
+            for rep in range(3):
+                x = torch.rand(B, 40, 40, 1, device="cuda", generator=g)
+                eps = torch.randn(B, 28, device="cuda", generator=g) if variant == "vae" else None
+                r0, l0 = net.forward(x, eps)
+                r1, l1 = net.forward_graphed(x, eps)
+                torch.cuda.synchronize()
+                assert torch.equal(r0, r1) and torch.equal(l0, l1), (variant, B, rep)
+    with pytest.raises(ValueError):
+        Net(28, "vae").forward_graphed(torch.rand(2, 40, 40, 1, device="cuda"))

@@ -43,3 +43,13 @@ for B in [int(a) for a in sys.argv[1:]] or [8, 64, 512]:
         host += time.perf_counter() - t0
     torch.cuda.synchronize()
     print(f"batch {B}: forward {wall * 1e3:.3f} ms wall, {host / 50 * 1e3:.3f} ms host enqueue", flush=True)
+    # the same forward replayed from a captured HIP graph (Net.forward_graphed; injected epsilon)
+    eps = torch.randn(B, 28, device="cuda")
+    for i in range(5):
+        net.forward_graphed(x, eps)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(200):
+        net.forward_graphed(x, eps)
+    torch.cuda.synchronize()
+    print(f"batch {B}: forward from a HIP graph {(time.perf_counter() - t0) / 200 * 1e3:.3f} ms wall", flush=True)
