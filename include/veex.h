@@ -34,6 +34,10 @@ typedef struct ihipStream_t* veexStream_t; /* == hipStream_t */
 #define VEEX_VARIANT_VAE 0 /* models.py: Encoder / Decoder / VAE */
 #define VEEX_VARIANT_AE 1  /* models_standard.py: EncoderStandard / DecoderStandard / Autoencoder */
 
+/* Version of the descriptor structs and entry points declared here; veex_abi_version() returns the version the
+ * LIBRARY was built with.  A caller compiled against an older header must refuse to run when the two differ:
+ * VeexGemmDesc grew (weight_t, out_bn) in version 2 and the library reads those fields. */
+#define VEEX_ABI_VERSION 3
 const char* veex_last_error(void);
 int veex_abi_version(void);
 
@@ -80,7 +84,10 @@ typedef struct VeexGemmDesc {
                               BatchNorm, nullable = plain rounding) or bf16(out) (epilogue 1) */
   const float* out_scale; const float* out_shift;
   int32_t out_channels;    /* power of two; out_scale index = col & (out_channels-1) */
-  int32_t reserved_;
+  int32_t struct_size;     /* sizeof(VeexGemmDesc) of the caller's header, or 0 = this header's.  Fields that start at
+                              or beyond struct_size are taken as NULL instead of being read (a caller built against
+                              the version-1 header, which ended after weight_bf16, passes a shorter struct).
+                              Zero-initialise the whole descriptor before filling it. */
   const void* weight_bf16; /* optional packed bf16 weights [tap][Cout][Cin] (veex_pack_weights_bf16): selects the
                               bf16-MFMA kernel (fp32 accumulate) when Cin % 32 == 0 and N*Hout*Wout >= 4096 */
   const float* weight_t;   /* optional, mode 0, fp32 engine: the same weights as [tap][Cout][Cin] (veex_transpose_weights_f32);
@@ -195,7 +202,9 @@ int veex_minmax(const float* x, long long n, float* partials, float* minmax, vee
  * the library (one copy per GPU, held until the process ends) instead of a caller buffer.  Limits: n <= 2^32
  * floats per call (larger n is rejected with VEEX_EINVAL); calls that overlap on ONE GPU (different streams) share
  * the array and race -- serialise them; the first call on a device resolves the array's address and must not be
- * made under stream capture.  Calls no hipMalloc / hipFree. */
+ * made under stream capture.  The CURRENT device of the calling thread must be the GPU that owns x and the stream
+ * (each GPU has its own copy of the array at its own address; the copy is looked up by the current device, and a
+ * device pointer x that belongs to another GPU is refused with VEEX_EINVAL).  Calls no hipMalloc / hipFree. */
 int veex_minmax_static(const float* x, long long n, float* minmax, veexStream_t s);
 int veex_normalize(const float* x, const float* minmax, float* out, long long n, veexStream_t s);
 int veex_denormalize(const float* x, const float* minmax, float* out, long long n, veexStream_t s);

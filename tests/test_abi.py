@@ -81,5 +81,17 @@ def test_bad_arguments_are_rejected_on_the_host(lib):
         d = GemmDesc()
         assert lib.veex_gather_gemm(C.byref(d), None) == -1
         assert lib.veex_adam(None, None, None, None, 7, None, None, 1e-3, 1.0, 0.9, 0.999, 1e-7, None) == -1
+        # struct_size: a descriptor of no known version is refused; a version-1 caller's shorter struct is accepted and
+        # the fields it does not have are not read (host-only planning call)
+        d.N, d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.Cout = 4, 8, 8, 32, 8, 8, 32
+        d.kh = d.kw = 3; d.stride = 1; d.mode = 0
+        d.inp = d.weight = d.out = 1 << 20                       # never dereferenced on the host
+        assert lib.veex_gather_gemm_m_tiles(C.byref(d)) > 0
+        d.struct_size = 8
+        assert lib.veex_gather_gemm_m_tiles(C.byref(d)) == -1 and b"struct_size" in lib.veex_last_error()
+        d.struct_size = GemmDesc.weight_bf16.offset + 8          # the version-1 struct ended here
+        d.out_bn = 0xdead0000                                    # garbage where a newer field sits: ignored
+        assert lib.veex_gather_gemm_m_tiles(C.byref(d)) > 0
+        assert lib.veex_abi_version() == 3
     finally:
         lib.veex_net_destroy(h)

@@ -62,6 +62,24 @@ def test_normalize_ragged_sizes_and_constant_input():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,where", [(1000 * 1600, 777_777), (4099, 4098), (5, 0), (1 << 22, (1 << 22) - 3)])
+def test_minmax_and_normalize_propagate_nan_like_numpy(n, where):
+    """np.min / np.max of an array that holds a NaN are NaN, and train.py:99-100 then gives NaN everywhere."""
+    from vae_eeg_xai_amd import dataio
+    x = np.random.default_rng(n).standard_normal(n).astype(np.float32)
+    x[where] = np.nan
+    mm = dataio.minmax(x).cpu().numpy()
+    assert np.isnan(mm).all() and np.isnan(x.min()) and np.isnan(x.max())
+    got = dataio.normalize(x).cpu().numpy()
+    with np.errstate(invalid="ignore"):
+        ref = (x - x.min()) / (x.max() - x.min())
+    assert np.isnan(ref).all() and np.isnan(got).all()
+    x[where] = np.inf                                            # an infinity is an ordinary maximum
+    mm = dataio.minmax(x).cpu().numpy()
+    assert mm[1] == np.inf and mm[0] == x.min()
+
+
+@pytest.mark.gpu
 def test_electrode_readout_matches_the_reference_gather():
     from vae_eeg_xai_amd import dataio
     B = 37

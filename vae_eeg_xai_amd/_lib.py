@@ -32,7 +32,7 @@ class GemmDesc(C.Structure):
         ("mode", C.c_int32), ("affine_channels", C.c_int32), ("affine_spatial", C.c_int32),
         ("epilogue", C.c_int32), ("relu", C.c_int32), ("e_channels", C.c_int32), ("nsplit", C.c_int32),
         ("in_bf16", C.c_void_p), ("out_bf16", C.c_void_p), ("out_scale", C.c_void_p), ("out_shift", C.c_void_p),
-        ("out_channels", C.c_int32), ("reserved_", C.c_int32),
+        ("out_channels", C.c_int32), ("struct_size", C.c_int32),
         ("weight_bf16", C.c_void_p), ("weight_t", C.c_void_p), ("out_bn", C.c_void_p),
     ]
 
@@ -111,6 +111,7 @@ SIGNATURES = {
     "veex_net_attribute": (_I, [_P, _P, _P, _P, _I, C.POINTER(_I), _I, _I, _P, _L, _P, _P]),
 }
 
+ABI_VERSION = 3               # VEEX_ABI_VERSION of include/veex.h
 F_PHILOX = 1
 F_ZMEAN_DECODE = 2
 VARIANT_VAE, VARIANT_AE = 0, 1
@@ -127,6 +128,8 @@ def _load():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args
+    if lib.veex_abi_version() != ABI_VERSION:   # descriptor structs below mirror ONE version of include/veex.h
+        raise VeexError(f"{LIB_PATH} has ABI version {lib.veex_abi_version()}, this binding is for {ABI_VERSION}: rebuild it")
     return lib
 
 

@@ -21,43 +21,68 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// NumPy's min / max PROPAGATE NaN (np.min of an array that holds a NaN is NaN; train.py:99-100 then normalises the
+// whole set to NaN), fminf / fmaxf DROP it: every element is also tested for v != v, and a block / the final fold that
+// saw one writes NaN for both extrema.
+__device__ __forceinline__ bool block_any(bool flag, int* s_flag) {   // s_flag: one LDS word, zeroed by thread 0 here
+  if (threadIdx.x == 0) *s_flag = 0;
+  __syncthreads();
+  if (__any(flag) && (threadIdx.x & 63) == 0) atomicOr(s_flag, 1);
+  __syncthreads();
+  return *s_flag != 0;
+}
+
 // pass 1: per-block (min, max) partials [blocks][2]; min/max are exact whatever the order
 __global__ __launch_bounds__(256) void minmax_partial_kernel(const float* __restrict__ x, long long n, float* __restrict__ part) {
   float lo = FLT_MAX, hi = -FLT_MAX;
+  bool bad = false;
   const long long n4 = n >> 2;
   const float4* x4 = reinterpret_cast<const float4*>(x);
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     const float4 v = x4[i];
     lo = fminf(fminf(lo, v.x), fminf(v.y, fminf(v.z, v.w)));
     hi = fmaxf(fmaxf(hi, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+    bad |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
   }
   if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {
     const float v = x[(n4 << 2) + threadIdx.x];
     lo = fminf(lo, v); hi = fmaxf(hi, v);
+    bad |= (v != v);
   }
   lo = wave_min(lo); hi = wave_max(hi);
   __shared__ float s[8];
+  __shared__ int s_bad;
+  const bool any_bad = block_any(bad, &s_bad);
   const int w = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { s[w] = lo; s[4 + w] = hi; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    part[2 * blockIdx.x] = fminf(fminf(s[0], s[1]), fminf(s[2], s[3]));
-    part[2 * blockIdx.x + 1] = fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7]));
+    const float qnan = __uint_as_float(0x7FC00000u);
+    part[2 * blockIdx.x] = any_bad ? qnan : fminf(fminf(s[0], s[1]), fminf(s[2], s[3]));
+    part[2 * blockIdx.x + 1] = any_bad ? qnan : fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7]));
   }
 }
 
 // pass 2: one block folds the partials into minmax[2]
 __global__ __launch_bounds__(256) void minmax_final_kernel(const float* __restrict__ part, int blocks, float* __restrict__ minmax) {
   float lo = FLT_MAX, hi = -FLT_MAX;
-  for (int i = threadIdx.x; i < blocks; i += 256) { lo = fminf(lo, part[2 * i]); hi = fmaxf(hi, part[2 * i + 1]); }
+  bool bad = false;
+  for (int i = threadIdx.x; i < blocks; i += 256) {
+    const float a = part[2 * i], b = part[2 * i + 1];
+    lo = fminf(lo, a); hi = fmaxf(hi, b);
+    bad |= (a != a) | (b != b);
+  }
   lo = wave_min(lo); hi = wave_max(hi);
   __shared__ float s[8];
+  __shared__ int s_bad;
+  const bool any_bad = block_any(bad, &s_bad);
   const int w = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { s[w] = lo; s[4 + w] = hi; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    minmax[0] = fminf(fminf(s[0], s[1]), fminf(s[2], s[3]));
-    minmax[1] = fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7]));
+    const float qnan = __uint_as_float(0x7FC00000u);
+    minmax[0] = any_bad ? qnan : fminf(fminf(s[0], s[1]), fminf(s[2], s[3]));
+    minmax[1] = any_bad ? qnan : fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7]));
   }
 }
 
@@ -142,9 +167,18 @@ static __device__ __align__(256) float scratch[2 * VEEX_MINMAX_STATIC_BLOCKS];
 static std::mutex g_scratch_mu;
 static float* g_scratch_ptr[VEEX_MAX_DEVICES];         // per device: the array's address ON THAT GPU (not the host-side name)
 
-static int scratch_of_current_device(float** out) {
+// The array of the GPU that owns `x`: the kernels run on the stream's device and must be handed THAT device's copy
+// of the array.  The caller's current device must be that GPU too (hipGetSymbolAddress and the launch both act on the
+// current device); a mismatch is refused instead of launching with another GPU's address.
+static int scratch_of_device_owning(const float* x, float** out) {
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= VEEX_MAX_DEVICES) { veex_set_error("minmax_static: no current device"); return -3; }
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, x) == hipSuccess && attr.type == hipMemoryTypeDevice && attr.device != dev) {
+    veex_set_error("minmax_static: x lives on GPU %d but the current device is %d (set the device that owns x and the stream)", attr.device, dev);
+    return -1;
+  }
+  (void)hipGetLastError();   // an unregistered pointer leaves a sticky error behind; the launch check below must not see it
   std::lock_guard<std::mutex> lk(g_scratch_mu);
   if (g_scratch_ptr[dev] == nullptr) {   // first call on this device (outside stream capture): resolve the symbol once
     void* p = nullptr;
@@ -165,7 +199,7 @@ int veex_minmax_static(const float* x, long long n, float* minmax, hipStream_t s
   const int blocks = veex_minmax_partial_blocks(n);
   if (blocks > VEEX_MINMAX_STATIC_BLOCKS) { veex_set_error("minmax_static: internal: %d blocks exceed the scratch array", blocks); return -1; }
   float* part = nullptr;
-  const int rc = scratch_of_current_device(&part);
+  const int rc = scratch_of_device_owning(x, &part);
   if (rc != 0) return rc;
   hipLaunchKernelGGL(minmax_partial_kernel, dim3(blocks), dim3(256), 0, st, x, n, part);
   hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(256), 0, st, part, blocks, minmax);

@@ -46,7 +46,7 @@ extern "C" void veexi_debug_reload_env(void) {
   std::lock_guard<std::mutex> lk(g_env_mu);
   g_env.clear();
 }
-extern "C" int veex_abi_version(void) { return 1; }
+extern "C" int veex_abi_version(void) { return VEEX_ABI_VERSION; }
 
 extern "C" int veexi_loss_finalize(const float*, const float*, const float*, int, double, float*, float*, float*, hipStream_t);
 extern "C" int veexi_attr_seed(const float*, const float*, float*, int, int, int, int, int, hipStream_t);
@@ -65,9 +65,15 @@ static inline int pow2_or_zero(int c) { return (c > 0 && (c & (c - 1)) == 0); }
 static int fill_gg(const VeexGemmDesc* d, GGParams& p) {
   if (d == nullptr) { veex_set_error("null descriptor"); return VEEX_EINVAL; }
   memset(&p, 0, sizeof(p));
-  p.A = d->in; p.W = d->weight; p.Wbf = d->weight_bf16; p.Wt = (d->mode == 0) ? d->weight_t : nullptr; p.Out = d->out;
+  // fields the caller's header does not have (struct_size, include/veex.h) are not read
+  const size_t have = (d->struct_size > 0) ? (size_t)d->struct_size : sizeof(VeexGemmDesc);
+  if (have < offsetof(VeexGemmDesc, weight_bf16) || have > sizeof(VeexGemmDesc)) { veex_set_error("gather_gemm: struct_size %d is not a VeexGemmDesc of any version", d->struct_size); return VEEX_EINVAL; }
+  const bool has_wbf = have >= offsetof(VeexGemmDesc, weight_bf16) + sizeof(void*);
+  const bool has_wt = have >= offsetof(VeexGemmDesc, weight_t) + sizeof(void*);
+  const bool has_obn = have >= offsetof(VeexGemmDesc, out_bn) + sizeof(void*);
+  p.A = d->in; p.W = d->weight; p.Wbf = has_wbf ? d->weight_bf16 : nullptr; p.Wt = (has_wt && d->mode == 0) ? d->weight_t : nullptr; p.Out = d->out;
   p.Abf = d->in_bf16; p.OutBf = d->out_bf16; p.o_scale = d->out_scale; p.o_shift = d->out_shift;
-  p.OutBn = (d->epilogue == VEEX_EPI_FWD) ? d->out_bn : nullptr;
+  p.OutBn = (has_obn && d->epilogue == VEEX_EPI_FWD) ? d->out_bn : nullptr;
   if (p.OutBn != nullptr && p.o_scale == nullptr) { veex_set_error("gather_gemm: out_bn needs out_scale / out_shift"); return VEEX_EINVAL; }
   if (p.o_scale != nullptr) {
     if (!pow2_or_zero(d->out_channels) || p.o_shift == nullptr) { veex_set_error("gather_gemm: out_channels must be a power of two and out_shift non-null"); return VEEX_EINVAL; }

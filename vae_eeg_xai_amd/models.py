@@ -24,22 +24,42 @@ from . import dist as vdist
 keras = tf.keras
 
 
-class DeviceArray:
+class DeviceArray(np.lib.mixins.NDArrayOperatorsMixin):
     """ndarray-protocol view of a device tensor: np.asarray / indexing / .shape / .reshape /
-    np.quantile / np.copy work as on the tensors the reference returns (analysis.py:38-52,243,492)."""
+    np.quantile / np.copy / arithmetic work as on the tensors the reference returns
+    (analysis.py:38-52,243,492).  The data stays in HBM until the host looks at it; the first host-side look
+    (np.asarray, a scalar index, arithmetic) copies it ONCE and later looks reuse that copy -- analysis.py:255-264,
+    323-333 index ``z_mean_blink[i, j]`` in O(N * L * quantiles) Python loops, which must not be one device
+    round trip each.  The wrapped tensor is treated as immutable (the library never writes into a returned tensor)."""
 
     __array_priority__ = 100
 
     def __init__(self, t: torch.Tensor):
         self._t = t
+        self._host = None
 
     # ndarray protocol
+    def _np(self):
+        if self._host is None:
+            self._host = self._t.detach().cpu().numpy()
+        return self._host
+
     def __array__(self, dtype=None, copy=None):
-        a = self._t.detach().cpu().numpy()
-        return a.astype(dtype) if dtype is not None else a
+        a = self._np()
+        if dtype is not None and np.dtype(dtype) != a.dtype:
+            return a.astype(dtype)
+        return a.copy() if copy else a
+
+    def __array_ufunc__(self, ufunc, method, *inputs, out=None, **kwargs):
+        # z - 1, z * mask, np.exp(z), z > q ...: NumPy on the cached host copy, like the ndarray-behaving tensors
+        # of the reference (np_config.enable_numpy_behavior, analysis.py:23)
+        if out is not None:
+            return NotImplemented
+        args = [i._np() if isinstance(i, DeviceArray) else i for i in inputs]
+        return getattr(ufunc, method)(*args, **kwargs)
 
     def numpy(self):
-        return self.__array__()
+        return self._np()
 
     @property
     def shape(self):
@@ -53,44 +73,85 @@ class DeviceArray:
     def ndim(self):
         return self._t.dim()
 
+    @property
+    def size(self):
+        return int(self._t.numel())
+
+    @property
+    def T(self):
+        return self._np().T
+
     def __len__(self):
         return self._t.shape[0]
 
     def __getitem__(self, idx):
-        # index in HBM and move only the selection (analysis.py indexes whole-set outputs per sample in Python
-        # loops, e.g. :46,:581: copying the set per index would be O(N^2) bytes)
-        try:
-            t = self._t[_device_index(idx, self._t.device)]
-        except (TypeError, ValueError, RuntimeError):
-            return self.__array__()[idx]          # index forms torch lacks (negative strides, ...)
-        a = t.detach().cpu().numpy()
-        return a[()] if a.ndim == 0 else a
+        # Scalars, slices and anything else once a host copy exists: plain NumPy on that copy (NumPy's own
+        # IndexError for an out-of-range index).  A fancy index (index array / mask) on a set that is still only in
+        # HBM is applied there and only the selection moves (analysis.py:46,581 pick rows of whole-set outputs) --
+        # after a host-side bounds check: an out-of-range index inside the device gather is a device-side assert
+        # that poisons the HIP context.
+        if self._host is None and _is_fancy(idx):
+            try:
+                tidx = _device_index(idx, self._t.device, self._t.shape)
+            except (TypeError, ValueError):
+                return self._np()[idx]            # index forms torch lacks
+            a = self._t[tidx].detach().cpu().numpy()
+            return a[()] if a.ndim == 0 else a
+        return self._np()[idx]
 
     def __iter__(self):
-        return iter(self.__array__())
+        return iter(self._np())
+
+    def __float__(self):
+        return float(self._np())
 
     def reshape(self, *shape):
-        return self.__array__().reshape(*shape)
+        return self._np().reshape(*shape)
+
+    def astype(self, dtype):
+        return self._np().astype(dtype)
 
     def copy(self):
-        return self.__array__().copy()
+        return self._np().copy()
+
+    def min(self, *a, **k): return self._np().min(*a, **k)
+    def max(self, *a, **k): return self._np().max(*a, **k)
+    def mean(self, *a, **k): return self._np().mean(*a, **k)
+    def sum(self, *a, **k): return self._np().sum(*a, **k)
+    def std(self, *a, **k): return self._np().std(*a, **k)
 
     def __repr__(self):
         return f"DeviceArray(shape={self.shape}, device={self._t.device})"
 
 
-def _device_index(idx, device):
-    """NumPy-style index -> torch index with array parts moved to the device."""
+def _is_fancy(idx):
+    parts = idx if isinstance(idx, tuple) else (idx,)
+    return any(isinstance(i, (list, np.ndarray, torch.Tensor, DeviceArray)) for i in parts)
+
+
+def _device_index(idx, device, shape, axis=0):
+    """NumPy-style index -> torch index with array parts bounds-checked on the host (IndexError like NumPy) and
+    moved to the device."""
     if isinstance(idx, tuple):
-        return tuple(_device_index(i, device) for i in idx)
+        if any(i is None or i is Ellipsis for i in idx):
+            raise TypeError("newaxis / Ellipsis: host path")
+        return tuple(_device_index(i, device, shape, k) for k, i in enumerate(idx))
     if isinstance(idx, DeviceArray):
-        idx = idx._t
+        idx = idx._np()
     if isinstance(idx, torch.Tensor):
-        return idx.to(device)
+        idx = idx.detach().cpu().numpy()
     if isinstance(idx, (list, np.ndarray)):
         a = np.asarray(idx)
-        if a.dtype != np.bool_:
+        n = int(shape[axis]) if axis < len(shape) else 0
+        if a.dtype == np.bool_:
+            if a.ndim != 1 or a.shape[0] != n:
+                raise TypeError("multi-dimensional or mis-sized mask: host path (NumPy raises what it raises)")
+        else:
+            if a.size and not np.issubdtype(a.dtype, np.integer):
+                raise IndexError("arrays used as indices must be of integer (or boolean) type")
             a = a.astype(np.int64)
+            if a.size and (a.min() < -n or a.max() >= n):
+                raise IndexError(f"index {int(a.max() if a.max() >= n else a.min())} is out of bounds for axis {axis} with size {n}")
         return torch.from_numpy(np.ascontiguousarray(a)).to(device)
     if isinstance(idx, np.integer):
         return int(idx)
@@ -113,8 +174,10 @@ def sample(z_mean, z_log_var, epsilon=None, generator=None):
     from ._lib import lib, check, ptr
     dev = torch.device("cuda", torch.cuda.current_device())
     keep_graph = any(isinstance(t, torch.Tensor) and t.requires_grad for t in (z_mean, z_log_var))
-    zm = z_mean.to(dev) if keep_graph else _as_device_f32(z_mean, dev)
-    zlv = z_log_var.to(dev) if keep_graph else _as_device_f32(z_log_var, dev)
+    # differentiable path: .float() here, in Python, so that autograd records the cast (a float64 / half input then
+    # gets its gradient back in its own dtype); the op itself only sees float32
+    zm = z_mean.to(dev).float() if keep_graph else _as_device_f32(z_mean, dev)
+    zlv = z_log_var.to(dev).float() if keep_graph else _as_device_f32(z_log_var, dev)
     B, L = zm.shape
     if epsilon is None:
         epsilon = _host_rng_eps((B, L), generator)

@@ -102,7 +102,7 @@ class Net:
         check(lib.veex_net_set_compute(self._h, _lib.COMPUTE_BF16 if compute == "bf16" else _lib.COMPUTE_F32),
               "net_set_compute")
         self.compute = compute
-        self._ws.clear()            # the workspace plan (split-K slabs) depends on the kernel family
+        self._drop_workspaces()     # the workspace plan (split-K slabs) depends on the kernel family
 
     def set_overlap(self, on: bool):
         """Run the weight-gradient GEMMs of the backward pass on a second HIP stream, concurrently
@@ -115,6 +115,7 @@ class Net:
         s = self._side_stream.cuda_stream if on else None
         check(lib.veex_net_set_side_stream(self._h, C.c_void_p(s) if s is not None else None), "net_set_side_stream")
         self.overlap = bool(on)
+        self._drop_graphs()         # a captured graph froze the old fork / join plan
 
     # ---------------- parameters ----------------
     def view(self, spec: TensorSpec, buf: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -201,15 +202,31 @@ class Net:
         check(lib.veex_net_set_batch_divisor(self._h, float(divisor)), "net_set_batch_divisor")
 
     # ---------------- workspace ----------------
+    def _drop_graphs(self):
+        """Forget every captured graph (forward_graphed, train_step_graphed): they hold raw pointers into the
+        workspaces and the compute mode / stream plan they were captured with."""
+        self.__dict__.pop("_fwd_graphs", None)
+        self.__dict__.pop("_train_graphs", None)
+
+    def _drop_workspaces(self):
+        self._ws.clear()
+        self._drop_graphs()
+
     def workspace(self, batch: int) -> torch.Tensor:
         ws = self._ws.get(batch)
         if ws is None:
             n = lib.veex_net_workspace_floats(self._h, batch)
             if n < 0:
                 raise _lib.VeexError(lib.veex_last_error().decode())
-            ws = torch.zeros(n, dtype=torch.float32, device=self.device)
+            # every region is written by a kernel before a kernel reads it: no zero fill (torch.zeros launched a
+            # FillFunctor over ~1 GB per new batch size)
+            ws = torch.empty(n, dtype=torch.float32, device=self.device)
             if len(self._ws) > 4:
-                self._ws.clear()
+                # evict the workspaces no captured graph points into (a graph entry keeps its own reference, so its
+                # memory stays valid either way; this only bounds what the cache itself holds)
+                pinned = {k[0] for k in self.__dict__.get("_fwd_graphs", {})} | set(self.__dict__.get("_train_graphs", {}))
+                for b in [b for b in self._ws if b not in pinned]:
+                    del self._ws[b]
             self._ws[batch] = ws
         return ws
 
@@ -332,8 +349,10 @@ class Net:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = self.forward(sx, dummy, zmean_decode=zmean_decode, first_sample=0)
-            ent = graphs[key] = (g, sx, se, out)
-        g, sx, se, out = ent
+            # the entry owns everything the graph's kernels point at: the workspace of this batch size and the
+            # zero epsilon of the zmean_decode key (both would otherwise go back to the caching allocator)
+            ent = graphs[key] = (g, sx, se, out, self.workspace(B), dummy)
+        g, sx, se, out = ent[:4]
         sx.copy_(x.reshape(sx.shape))
         if se is not None:
             se.copy_(e)

@@ -219,6 +219,7 @@ def _check_layer_args(x: Tensor, w: Tensor, stride: int):
 def _gemm(mode: int, a: Tensor, w: Tensor, bias: Optional[Tensor], out: Tensor, cin: int, cout: int, k: int,
           stride: int, pad_begin: int, relu: bool, what: str) -> None:
     d = _lib.GemmDesc()
+    d.struct_size = C.sizeof(_lib.GemmDesc)
     d.inp, d.weight, d.out, d.bias = ptr(a), ptr(w), ptr(out), ptr(bias)
     d.N, d.Hin, d.Win, d.Cin = a.shape[0], a.shape[1], a.shape[2], cin
     d.Hout, d.Wout, d.Cout = out.shape[1], out.shape[2], cout
