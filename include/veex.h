@@ -152,6 +152,11 @@ int veex_conv1_dgrad(const float* dpre, const float* w, const float* mul, float*
 int veex_deconv6_bce_fwd(const float* a5, const float* scale, const float* shift, const float* w6, const float* b6,
                          const float* target, float* logits, float* recon, float* dlogit, float* rec_b,
                          float* dlsum_b, int batch, float inv_batch, veexStream_t s);
+/* same with the form of the cross-entropy selectable: VEEX_BCE_LOGITS (what veex_deconv6_bce_fwd computes) or
+ * VEEX_BCE_PROBS, keras.backend.binary_crossentropy on the clipped probabilities -- see veex_net_set_semantics */
+int veex_deconv6_bce_fwd_form(const float* a5, const float* scale, const float* shift, const float* w6, const float* b6,
+                              const float* target, float* logits, float* recon, float* dlogit, float* rec_b,
+                              float* dlsum_b, int batch, float inv_batch, int bce_form, veexStream_t s);
 /* backward of deconv6 fused with BatchNorm/ReLU backward of deconv5; slab [batch][7][64]:
  * rows 0-3 dW6 partials, rows 4-6 the three column sums of veex_colsum_finalize */
 int veex_deconv6_bwd(const float* dlogit, const float* a5, const float* scale, const float* shift, const float* w6,
@@ -256,6 +261,20 @@ long long veex_net_ws_offset(const VeexNet* net, int batch, const char* name, lo
 #define VEEX_COMPUTE_F32 0
 #define VEEX_COMPUTE_BF16 1
 int veex_net_set_compute(VeexNet* net, int compute);
+
+/* The two Keras 2.13 behaviours of models.py:152-160 that nothing in the reference tree can pin (parity unpinned;
+ * SURVEY Appendix A.3 / A.4), each with its alternative one switch away.  Defaults = the survey's reading.
+ *  bn_mode  VEEX_BN_INFERENCE: BatchNormalization normalises with its moving statistics inside train_step too (the
+ *           reference never forwards `training`);  VEEX_BN_BATCH: batch mean / biased variance, gradients through the
+ *           statistics, moving statistics updated with momentum 0.99 by veex_net_train_fwd_bwd (which then WRITES
+ *           the state buffer); encode / decode / forward / attribute keep using the moving statistics.  fp32 engine.
+ *  bce_form VEEX_BCE_LOGITS: sigmoid_cross_entropy_with_logits (Keras finds the sigmoid's cached logits);
+ *           VEEX_BCE_PROBS: -(t log(p + 1e-7) + (1 - t) log(1 - p + 1e-7)), p = clip(sigmoid(a), 1e-7, 1 - 1e-7). */
+#define VEEX_BN_INFERENCE 0
+#define VEEX_BN_BATCH 1
+#define VEEX_BCE_LOGITS 0
+#define VEEX_BCE_PROBS 1
+int veex_net_set_semantics(VeexNet* net, int bn_mode, int bce_form);
 
 /* Optional second stream (caller-owned, same device): veex_net_train_fwd_bwd then runs every weight-gradient GEMM
  * and its slab reduction there, concurrently with the input-gradient chain on the main stream, and makes the main

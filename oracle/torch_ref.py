@@ -30,7 +30,14 @@ def to_torch(params: dict, dtype=torch.float64, requires_grad=True):
     return out
 
 
-def _bn(a, p, prefix):
+def _bn(a, p, prefix, sem=None):
+    """BatchNormalization after layer ``prefix``: moving statistics (default) or, with sem bn="batch", the batch's
+    own mean and biased variance with autograd flowing through them (vae_oracle.DEFAULT_SEM)."""
+    if sem is not None and sem["bn"] == "batch":
+        dims = tuple(range(a.dim() - 1))
+        mu = a.mean(dim=dims)
+        var = a.var(dim=dims, unbiased=False)
+        return (a - mu) * torch.rsqrt(var + vo.BN_EPS) * p[prefix + ".gamma"] + p[prefix + ".beta"]
     rstd = torch.rsqrt(p[prefix + ".var"] + vo.BN_EPS)
     return (a - p[prefix + ".mean"]) * rstd * p[prefix + ".gamma"] + p[prefix + ".beta"]
 
@@ -64,7 +71,7 @@ def _relu(pre_nhwc, masks, layer):
     return pre_nhwc * m
 
 
-def encoder(p, x_nhwc, variant="vae", masks=None):
+def encoder(p, x_nhwc, variant="vae", masks=None, sem=None):
     h = x_nhwc.permute(0, 3, 1, 2)
     acts = {}
     for name, cin, cout, k, s, pad in vo.ENC_CONVS:
@@ -72,7 +79,7 @@ def encoder(p, x_nhwc, variant="vae", masks=None):
         acts[f"enc.{name}.pre"] = pre
         a = _relu(pre, masks, f"enc.{name}")
         acts[f"enc.{name}.a"] = a
-        h = _bn(a, p, f"enc.{name}").permute(0, 3, 1, 2)
+        h = _bn(a, p, f"enc.{name}", sem).permute(0, 3, 1, 2)
     flat = h.permute(0, 2, 3, 1).reshape(h.shape[0], -1)
     pre = flat @ p["enc.dense.kernel"] + p["enc.dense.bias"]
     acts["enc.dense.pre"] = pre
@@ -85,12 +92,12 @@ def encoder(p, x_nhwc, variant="vae", masks=None):
     return d, None, acts
 
 
-def decoder(p, z, masks=None, acts=None):
+def decoder(p, z, masks=None, acts=None, sem=None):
     pre = z @ p["dec.dense.kernel"] + p["dec.dense.bias"]
     if acts is not None:
         acts["dec.dense.pre"] = pre
     a = _relu(pre, masks, "dec.dense")
-    h = _bn(a, p, "dec.dense").reshape(-1, 4, 4, 256).permute(0, 3, 1, 2)
+    h = _bn(a, p, "dec.dense", sem).reshape(-1, 4, 4, 256).permute(0, 3, 1, 2)
     for name, cin, cout, k, s, pad in vo.DEC_DECONVS:
         pre = _deconv(h, p[f"dec.{name}.kernel"], p[f"dec.{name}.bias"], s, pad).permute(0, 2, 3, 1)
         if name == "deconv6":
@@ -98,19 +105,24 @@ def decoder(p, z, masks=None, acts=None):
         if acts is not None:
             acts[f"dec.{name}.pre"] = pre
         a = _relu(pre, masks, f"dec.{name}")
-        h = _bn(a, p, f"dec.{name}").permute(0, 3, 1, 2)
+        h = _bn(a, p, f"dec.{name}", sem).permute(0, 3, 1, 2)
 
 
-def losses(p, x, eps=None, variant="vae", masks=None, acts=None):
-    zm, zlv, enc_acts = encoder(p, x, variant, masks)
+def losses(p, x, eps=None, variant="vae", masks=None, acts=None, sem=None):
+    sem = vo.resolve_sem(sem)
+    zm, zlv, enc_acts = encoder(p, x, variant, masks, sem)
     if acts is not None:
         acts.update(enc_acts)
     if variant == "vae":
         z = zm + torch.exp(0.5 * zlv) * eps
     else:
         z = zm
-    logits = decoder(p, z, masks, acts)
-    bce = torch.clamp(logits, min=0) - logits * x + torch.log1p(torch.exp(-logits.abs()))
+    logits = decoder(p, z, masks, acts, sem)
+    if sem["bce"] == "probs":      # clipped-probability form; torch.clamp passes no gradient outside its range, like TF
+        pr = torch.clamp(torch.sigmoid(logits), vo.BCE_CLIP, 1.0 - vo.BCE_CLIP)
+        bce = -(x * torch.log(pr + vo.BCE_CLIP) + (1.0 - x) * torch.log(1.0 - pr + vo.BCE_CLIP))
+    else:
+        bce = torch.clamp(logits, min=0) - logits * x + torch.log1p(torch.exp(-logits.abs()))
     rec = bce.mean(dim=-1).sum(dim=(1, 2)).mean()
     if variant == "vae":
         kl = (-0.5 * (1 + zlv - zm ** 2 - torch.exp(zlv))).sum(dim=1).mean()
@@ -119,7 +131,7 @@ def losses(p, x, eps=None, variant="vae", masks=None, acts=None):
     return rec + kl, rec, kl, logits
 
 
-def pre_activations(params_np: dict, x_np, eps_np=None, variant="vae", dtype=torch.float64):
+def pre_activations(params_np: dict, x_np, eps_np=None, variant="vae", dtype=torch.float64, sem=None):
     """{layer + ".pre": ndarray} of every ReLU layer (what tests/util.device_masks compares the device's
     ReLU decisions with), plus "logits"."""
     p = to_torch(params_np, dtype, requires_grad=False)
@@ -127,18 +139,18 @@ def pre_activations(params_np: dict, x_np, eps_np=None, variant="vae", dtype=tor
     eps = None if eps_np is None else torch.tensor(np.asarray(eps_np), dtype=dtype)
     acts = {}
     with torch.no_grad():
-        total, rec, kl, logits = losses(p, x, eps, variant, None, acts)
+        total, rec, kl, logits = losses(p, x, eps, variant, None, acts, sem)
     out = {k: v.numpy() for k, v in acts.items() if k.endswith(".pre")}
     out["logits"] = logits.numpy()
     return out
 
 
-def grads(params_np: dict, x_np, eps_np=None, variant="vae", dtype=torch.float64, masks=None):
+def grads(params_np: dict, x_np, eps_np=None, variant="vae", dtype=torch.float64, masks=None, sem=None):
     """Returns (total, rec, kl, {name: grad ndarray}) via autograd."""
     p = to_torch(params_np, dtype)
     x = torch.tensor(np.asarray(x_np), dtype=dtype)
     eps = None if eps_np is None else torch.tensor(np.asarray(eps_np), dtype=dtype)
-    total, rec, kl, logits = losses(p, x, eps, variant, masks)
+    total, rec, kl, logits = losses(p, x, eps, variant, masks, sem=sem)
     names = [k for k, t in p.items() if t.requires_grad]
     gs = torch.autograd.grad(total, [p[k] for k in names])
     return float(total.detach()), float(rec.detach()), float(kl.detach()), {k: g.numpy() for k, g in zip(names, gs)}

@@ -13,6 +13,29 @@ from __future__ import annotations
 import numpy as np
 
 BN_EPS = 1e-3          # keras BatchNormalization default epsilon [KERAS-SEM]
+BN_MOMENTUM = 0.99     # keras BatchNormalization default momentum [KERAS-SEM]
+BCE_CLIP = 1e-7        # keras.backend.epsilon(): clip and log offset of the probability-form BCE [KERAS-SEM]
+
+# The two Keras semantics of the path that nothing in /root/reference can pin (SURVEY 7 "Hard parts", A.3, A.4), each
+# with its alternative one switch away.  The DEFAULT is what the survey reads out of Keras 2.13 for models.py:
+#   bn  = "inference": train_step calls self.encoder(data) / self.decoder(z) without ``training`` (models.py:152-153),
+#         so BatchNormalization normalises with its moving statistics (frozen at 0 / 1) also inside fit();
+#         "batch": the layer normalises with the statistics of the batch (biased variance), updates the moving
+#         statistics with momentum 0.99, and gradients flow through the statistics (what training=True would do);
+#   bce = "logits": keras.losses.binary_crossentropy finds the sigmoid's cached ``_keras_logits`` and evaluates
+#         tf.nn.sigmoid_cross_entropy_with_logits; "probs": the fallback on the clipped probabilities,
+#         -(t*log(p+1e-7) + (1-t)*log(1-p+1e-7)) with p = clip(sigmoid(a), 1e-7, 1-1e-7).
+DEFAULT_SEM = {"bn": "inference", "bce": "logits"}
+SEM_CHOICES = {"bn": ("inference", "batch"), "bce": ("logits", "probs")}
+
+
+def resolve_sem(sem=None):
+    d = dict(DEFAULT_SEM)
+    for k, v in (sem or {}).items():
+        if k not in SEM_CHOICES or v not in SEM_CHOICES[k]:
+            raise ValueError(f"unknown Keras-semantics switch {k}={v!r}; choices: {SEM_CHOICES}")
+        d[k] = v
+    return d
 ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-7   # keras legacy Adam defaults [KERAS-SEM]
 
 # ----------------------------------------------------------------------------
@@ -243,6 +266,72 @@ def bn_bwd(a, gamma, mean, var, dy):
     return dy * gamma * rstd, dgamma, dbeta
 
 
+def bn_fwd_batch(a, gamma, beta):
+    """BatchNormalization with training=True [KERAS-SEM]: batch mean and BIASED variance over every axis but the
+    last.  Returns (y, mean, var)."""
+    axes = tuple(range(a.ndim - 1))
+    mu = a.mean(axis=axes)
+    var = a.var(axis=axes)
+    rstd = 1.0 / np.sqrt(var + BN_EPS)
+    return (a - mu) * rstd * gamma + beta, mu, var
+
+
+def bn_bwd_batch(a, gamma, mu, var, dy):
+    """Backward of bn_fwd_batch THROUGH the statistics: da = rstd * (g - mean(g) - xhat * mean(g * xhat)),
+    g = dy * gamma."""
+    axes = tuple(range(dy.ndim - 1))
+    rstd = 1.0 / np.sqrt(var + BN_EPS)
+    xhat = (a - mu) * rstd
+    dgamma = (dy * xhat).sum(axis=axes)
+    dbeta = dy.sum(axis=axes)
+    g = dy * gamma
+    da = rstd * (g - g.mean(axis=axes) - xhat * (g * xhat).mean(axis=axes))
+    return da, dgamma, dbeta
+
+
+def bn_moving_update(moving_mean, moving_var, mu, var, n_reduced, four_d):
+    """Moving statistics after one training=True call [KERAS-SEM]: moving <- moving * 0.99 + batch * 0.01; the 4-D
+    (fused) layers feed the UNBIASED batch variance (n / (n - 1)), the 2-D BatchNormalization after dec.dense the
+    biased one."""
+    v = var * (n_reduced / max(n_reduced - 1, 1)) if four_d else var
+    return (moving_mean * BN_MOMENTUM + mu * (1 - BN_MOMENTUM), moving_var * BN_MOMENTUM + v * (1 - BN_MOMENTUM))
+
+
+def _bn_apply(c, p, prefix, a, sem):
+    """The BatchNormalization after layer ``prefix`` in the selected mode; caches what the backward needs and, in
+    batch mode, the moving statistics the step leaves behind (c["bn_state"])."""
+    if sem["bn"] == "inference":
+        return bn_fwd(a, p[prefix + ".gamma"], p[prefix + ".beta"], p[prefix + ".mean"], p[prefix + ".var"])
+    y, mu, var = bn_fwd_batch(a, p[prefix + ".gamma"], p[prefix + ".beta"])
+    c[prefix + ".bn_mu"], c[prefix + ".bn_var"] = mu, var
+    n_red = a.size // a.shape[-1]
+    mm, mv = bn_moving_update(p[prefix + ".mean"], p[prefix + ".var"], mu, var, n_red, a.ndim == 4)
+    c.setdefault("bn_state", {})[prefix + ".mean"] = mm
+    c["bn_state"][prefix + ".var"] = mv
+    return y
+
+
+def _bn_back(c, p, prefix, a, dy, sem):
+    if sem["bn"] == "inference":
+        return bn_bwd(a, p[prefix + ".gamma"], p[prefix + ".mean"], p[prefix + ".var"], dy)
+    return bn_bwd_batch(a, p[prefix + ".gamma"], c[prefix + ".bn_mu"], c[prefix + ".bn_var"], dy)
+
+
+def bce_probs(a, t):
+    """keras.backend.binary_crossentropy on probabilities [KERAS-SEM] (the fallback form)."""
+    pr = np.clip(sigmoid(a), BCE_CLIP, 1.0 - BCE_CLIP)
+    return -(t * np.log(pr + BCE_CLIP) + (1.0 - t) * np.log(1.0 - pr + BCE_CLIP))
+
+
+def bce_probs_dlogit(a, t):
+    """d bce_probs / d a: zero where the clip is active (tf.clip_by_value passes no gradient outside its range)."""
+    sg = sigmoid(a)
+    inside = (sg >= BCE_CLIP) & (sg <= 1.0 - BCE_CLIP)
+    pr = np.clip(sg, BCE_CLIP, 1.0 - BCE_CLIP)
+    dpr = -t / (pr + BCE_CLIP) + (1.0 - t) / (1.0 - pr + BCE_CLIP)
+    return dpr * sg * (1.0 - sg) * inside
+
+
 def bce_logits(a, t):
     """tf.nn.sigmoid_cross_entropy_with_logits, reached via the _keras_logits shortcut
     of keras.losses.binary_crossentropy (models.py:156-160) [KERAS-SEM]."""
@@ -256,15 +345,16 @@ def sigmoid(a):
 # ----------------------------------------------------------------------------
 # model forward / backward
 # ----------------------------------------------------------------------------
-def encoder_fwd(p, x, variant="vae"):
+def encoder_fwd(p, x, variant="vae", sem=None):
     """Encoder.call (models.py:244-253) / EncoderStandard.call (models_standard.py:110-116).
     Layer order Conv(+bias) -> ReLU -> BN (models.py:219-223)."""
+    sem = resolve_sem(sem)
     c = {"x": x}
     h = x
     for name, cin, cout, k, s, pad in ENC_CONVS:
         pre = conv2d_fwd(h, p[f"enc.{name}.kernel"], p[f"enc.{name}.bias"], s, pad)
         a = np.maximum(pre, 0)
-        h = bn_fwd(a, p[f"enc.{name}.gamma"], p[f"enc.{name}.beta"], p[f"enc.{name}.mean"], p[f"enc.{name}.var"])
+        h = _bn_apply(c, p, f"enc.{name}", a, sem)
         c[f"enc.{name}.pre"] = pre
         c[f"enc.{name}.a"] = a
         c[f"enc.{name}.y"] = h
@@ -285,15 +375,16 @@ def sample(z_mean, z_log_var, eps):
     return z_mean + np.exp(0.5 * z_log_var) * eps
 
 
-def decoder_fwd(p, z, c=None):
+def decoder_fwd(p, z, c=None, sem=None):
     """Decoder.call (models.py:303-312): Dense relu -> BN -> reshape (4,4,256) -> 5x[deconv relu BN] -> deconv6."""
+    sem = resolve_sem(sem)
     c = {} if c is None else c
     c["z"] = z
     pre = z @ p["dec.dense.kernel"] + p["dec.dense.bias"]
     a = np.maximum(pre, 0)
     c["dec.dense.pre"] = pre
     c["dec.dense.a"] = a
-    h = bn_fwd(a, p["dec.dense.gamma"], p["dec.dense.beta"], p["dec.dense.mean"], p["dec.dense.var"])
+    h = _bn_apply(c, p, "dec.dense", a, sem)
     h = h.reshape(-1, 4, 4, 256)
     for name, cin, cout, k, s, pad in DEC_DECONVS:
         c[f"dec.{name}.in"] = h
@@ -305,23 +396,25 @@ def decoder_fwd(p, z, c=None):
         a = np.maximum(pre, 0)
         c[f"dec.{name}.pre"] = pre
         c[f"dec.{name}.a"] = a
-        h = bn_fwd(a, p[f"dec.{name}.gamma"], p[f"dec.{name}.beta"], p[f"dec.{name}.mean"], p[f"dec.{name}.var"])
+        h = _bn_apply(c, p, f"dec.{name}", a, sem)
     return c
 
 
-def forward(p, x, eps=None, variant="vae"):
+def forward(p, x, eps=None, variant="vae", sem=None):
     """VAE.train_step forward half (models.py:152-163) / Autoencoder (models_standard.py:36-44).
     Returns cache with all intermediates plus rec_loss, kl_loss, total."""
+    sem = resolve_sem(sem)
     x = np.asarray(x, dtype=np.float64)
-    c = encoder_fwd(p, x, variant)
+    c = encoder_fwd(p, x, variant, sem)
+    c["sem"] = sem
     if variant == "vae":
         c["eps"] = np.asarray(eps, dtype=np.float64)
         z = sample(c["z_mean"], c["z_log_var"], c["eps"])
     else:
         z = c["enc.dense.a"]
-    decoder_fwd(p, z, c)
+    decoder_fwd(p, z, c, sem)
     B = x.shape[0]
-    bce = bce_logits(c["logits"], x).mean(axis=-1)               # mean over last axis (size 1)
+    bce = (bce_logits if sem["bce"] == "logits" else bce_probs)(c["logits"], x).mean(axis=-1)   # mean over last axis (size 1)
     c["rec_per_sample"] = bce.sum(axis=(1, 2))
     c["rec_loss"] = c["rec_per_sample"].mean()
     if variant == "vae":
@@ -343,27 +436,29 @@ def backward(p, c, variant="vae", masks=None):
     checking that every disagreement sits at such a kink."""
     g = {}
     masks = masks or {}
+    sem = c.get("sem", resolve_sem(None))       # the switches the forward cache was made with
 
     def on(layer, a):
         return masks[layer] if layer in masks else (a > 0)
     x = c["x"]
     B = x.shape[0]
-    dh = (sigmoid(c["logits"]) - x) / B                           # d rec / d logits (SURVEY A.4)
+    if sem["bce"] == "logits":
+        dh = (sigmoid(c["logits"]) - x) / B                       # d rec / d logits (SURVEY A.4)
+    else:
+        dh = bce_probs_dlogit(c["logits"], x) / B
     g["dlogits"] = dh
     # decoder backwards
     for name, cin, cout, k, s, pad in reversed(DEC_DECONVS):
         if name != "deconv6":
             a = c[f"dec.{name}.a"]
-            da, g[f"dec.{name}.gamma"], g[f"dec.{name}.beta"] = bn_bwd(
-                a, p[f"dec.{name}.gamma"], p[f"dec.{name}.mean"], p[f"dec.{name}.var"], dh)
+            da, g[f"dec.{name}.gamma"], g[f"dec.{name}.beta"] = _bn_back(c, p, f"dec.{name}", a, dh, sem)
             dh = da * on(f"dec.{name}", a)
         g[f"dpre.dec.{name}"] = dh
         dh, g[f"dec.{name}.kernel"], g[f"dec.{name}.bias"] = deconv2d_bwd(
             c[f"dec.{name}.in"], p[f"dec.{name}.kernel"], dh, s, pad)
     dh = dh.reshape(B, 4096)
     a = c["dec.dense.a"]
-    da, g["dec.dense.gamma"], g["dec.dense.beta"] = bn_bwd(
-        a, p["dec.dense.gamma"], p["dec.dense.mean"], p["dec.dense.var"], dh)
+    da, g["dec.dense.gamma"], g["dec.dense.beta"] = _bn_back(c, p, "dec.dense", a, dh, sem)
     dpre = da * on("dec.dense", a)
     g["dpre.dec.dense"] = dpre
     g["dec.dense.kernel"] = c["z"].T @ dpre
@@ -390,8 +485,7 @@ def backward(p, c, variant="vae", masks=None):
     dh = (dpre @ p["enc.dense.kernel"].T).reshape(B, 5, 5, 256)
     for name, cin, cout, k, s, pad in reversed(ENC_CONVS):
         a = c[f"enc.{name}.a"]
-        da, g[f"enc.{name}.gamma"], g[f"enc.{name}.beta"] = bn_bwd(
-            a, p[f"enc.{name}.gamma"], p[f"enc.{name}.mean"], p[f"enc.{name}.var"], dh)
+        da, g[f"enc.{name}.gamma"], g[f"enc.{name}.beta"] = _bn_back(c, p, f"enc.{name}", a, dh, sem)
         dpre = da * on(f"enc.{name}", a)
         g[f"dpre.enc.{name}"] = dpre
         xin = c["x"] if name == "conv1" else c[f"enc.conv{int(name[-1]) - 1}.y"]
@@ -449,12 +543,15 @@ def trainable_names(latent_dim, variant="vae"):
     return [n for n, s, t in param_spec(latent_dim, variant) if t]
 
 
-def train_step(p, m, v, t, lr, x, eps=None, variant="vae"):
-    """One VAE.train_step (models.py:148-180): returns (total, rec, kl); updates p, m, v in place."""
-    c = forward(p, x, eps, variant)
+def train_step(p, m, v, t, lr, x, eps=None, variant="vae", sem=None):
+    """One VAE.train_step (models.py:148-180): returns (total, rec, kl); updates p, m, v in place (and, with
+    sem bn="batch", the BatchNormalization moving statistics)."""
+    c = forward(p, x, eps, variant, sem)
     g = backward(p, c, variant)
     names = trainable_names(p["dec.dense.kernel"].shape[0], variant)
     adam_step(p, {k: g[k] for k in names}, m, v, t, lr)
+    for k, val in c.get("bn_state", {}).items():
+        p[k] = val
     return c["total"], c["rec_loss"], c["kl_loss"]
 
 

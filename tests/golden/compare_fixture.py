@@ -26,9 +26,29 @@ def compare(got_path, want_path, rtol=1e-5):
     return n, bad
 
 
+def which_semantics(got_path, want_path, rtol=1e-5):
+    """``got`` against the committed fixture AND its alternate-[KERAS-SEM] siblings (``<fixture>__bn-batch.npz``,
+    ``__bce-probs.npz``, ``__bn-batch+bce-probs.npz``, made by make_golden.py): returns [(flags, keys, bad)], so
+    that a real TF run that does not follow the default reading names the switches to flip
+    (Net.set_semantics / veex_net_set_semantics) instead of just failing."""
+    import os
+    out = [("bn=inference bce=logits (default)",) + compare(got_path, want_path, rtol)]
+    for tag, flags in (("bn-batch", "bn=batch bce=logits"), ("bce-probs", "bn=inference bce=probs"),
+                       ("bn-batch+bce-probs", "bn=batch bce=probs")):
+        alt = want_path[:-4] + "__" + tag + ".npz"
+        if os.path.exists(alt):
+            out.append((flags,) + compare(got_path, alt, rtol))
+    return out
+
+
 if __name__ == "__main__":
-    n, bad = compare(sys.argv[1], sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 1e-5)
-    print(f"{n} keys compared, {len(bad)} outside tolerance")
+    rtol = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-5
+    res = which_semantics(sys.argv[1], sys.argv[2], rtol)
+    for flags, n, bad in res:
+        print(f"[{flags}] {n} keys compared, {len(bad)} outside tolerance")
+    match = [flags for flags, n, bad in res if n > 0 and not bad]
+    print("MATCHES: " + (", ".join(match) if match else "none of the Keras-semantics flag sets"))
+    n, bad = res[0][1], res[0][2]
     for b in bad:
         print("  ", b)
     sys.exit(1 if bad or n == 0 else 0)

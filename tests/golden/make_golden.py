@@ -18,11 +18,16 @@ from oracle import vae_oracle as vo  # noqa: E402
 CASES = [("vae", 28, 2, 11), ("ae", 28, 2, 12), ("vae", 8, 3, 13)]
 
 
-def build(variant, L, B, seed):
+# the alternate [KERAS-SEM] readings (oracle/vae_oracle.py DEFAULT_SEM): one small fixture each, same inputs, so that
+# compare_fixture.py can say WHICH reading a real TF run follows
+ALT_SEMS = {"bn-batch": {"bn": "batch"}, "bce-probs": {"bce": "probs"}, "bn-batch+bce-probs": {"bn": "batch", "bce": "probs"}}
+
+
+def build(variant, L, B, seed, sem=None):
     p = vo.init_params(L, variant, seed=seed, jitter=0.1)
     x = vo.synth_topomaps(B, seed + 100)
     eps = np.random.default_rng(seed + 200).standard_normal((B, L)).astype(np.float32) if variant == "vae" else None
-    c = vo.forward(p, x, eps, variant)
+    c = vo.forward(p, x, eps, variant, sem)
     g = vo.backward(p, c, variant)
     out = {"x": x, "total": c["total"], "rec_loss": c["rec_loss"], "kl_loss": c["kl_loss"],
            "logits": c["logits"].astype(np.float64), "recon": c["recon"], "z": c["z"],
@@ -39,11 +44,14 @@ def build(variant, L, B, seed):
     v = {k: np.zeros_like(p[k]) for k in names}
     pp = {k: a.copy() for k, a in p.items()}
     for t in (1, 2, 3):
-        tot, rec, kl = vo.train_step(pp, m, v, t, 1e-3, x, eps, variant)
+        tot, rec, kl = vo.train_step(pp, m, v, t, 1e-3, x, eps, variant, sem)
         out[f"loss_step{t}"] = tot
         if t in (1, 3):
             for k in ("enc.conv2.kernel", "dec.deconv4.kernel", "dec.dense.gamma", "enc.conv1.bias"):
                 out[f"p{t}.{k}"] = pp[k].ravel()[:32].copy()
+    if sem is not None:                 # alternate reading: the scalars and gradient digests only
+        return {k: v for k, v in out.items() if k.split(".")[0] in ("total", "rec_loss", "kl_loss", "gsum", "gabs", "ghead")
+                or k.startswith("loss_step") or k in ("recon", "z_mean", "z_log_var")}
     units = [0, 5, L - 1]
     out["units"] = np.array(units)
     out["saliency"] = vo.attribution(p, x, units, variant)[..., 0]
@@ -56,3 +64,7 @@ if __name__ == "__main__":
         path = os.path.join(HERE, f"{variant}_L{L}_B{B}_s{seed}.npz")
         np.savez_compressed(path, **build(variant, L, B, seed))
         print(path, os.path.getsize(path))
+        for tag, sem in ALT_SEMS.items():
+            apath = os.path.join(HERE, f"{variant}_L{L}_B{B}_s{seed}__{tag}.npz")
+            np.savez_compressed(apath, **build(variant, L, B, seed, sem))
+            print(apath, os.path.getsize(apath))

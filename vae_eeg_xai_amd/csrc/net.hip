@@ -117,6 +117,14 @@ extern "C" int veex_gather_gemm(const VeexGemmDesc* d, veexStream_t stream) {
   return veex_launch_gather_gemm(p, stream);
 }
 
+int veex_hg_describe(const GGParams& p, long long* out8);   // halo_gemm_bf16.hip
+// measurement aid: the halo-tile plan of this launch (0 = the halo kernel does not take it)
+extern "C" int veexi_debug_hg_plan(const VeexGemmDesc* d, long long* out8) {
+  GGParams p;
+  if (fill_gg(d, p) != 0 || out8 == nullptr) return -1;
+  return veex_hg_describe(p, out8);
+}
+
 extern "C" int veex_gather_gemm_m_tiles(const VeexGemmDesc* d) {
   GGParams p;
   if (fill_gg(d, p) != 0) return -1;
@@ -179,6 +187,7 @@ struct VeexNet {
   int L, variant, H1;
   int compute;                  // VEEX_COMPUTE_F32 / VEEX_COMPUTE_BF16
   double batch_div = 0.0;       // divisor of the batch-mean loss; 0 = the batch of the call (veex_net_set_batch_divisor)
+  int bn_mode = VEEX_BN_INFERENCE, bce_form = VEEX_BCE_LOGITS;   // the two unpinned Keras readings (veex_net_set_semantics)
   hipStream_t side = nullptr;   // optional caller-owned second stream for the weight-gradient GEMMs
   mutable hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   mutable int ev_next = 0;      // fork / join events (host objects, created by veex_net_set_side_stream)
@@ -345,7 +354,16 @@ extern "C" int veex_net_set_side_stream(VeexNet* n, veexStream_t side) {
 }
 extern "C" int veex_net_set_compute(VeexNet* n, int compute) {
   if (n == nullptr || (compute != VEEX_COMPUTE_F32 && compute != VEEX_COMPUTE_BF16)) { veex_set_error("set_compute: bad arguments"); return VEEX_EINVAL; }
+  if (compute != VEEX_COMPUTE_F32 && n->bn_mode == VEEX_BN_BATCH) { veex_set_error("set_compute: batch-statistics BatchNorm runs on the fp32 engine only"); return VEEX_EINVAL; }
   n->compute = compute;
+  return 0;
+}
+extern "C" int veex_net_set_semantics(VeexNet* n, int bn_mode, int bce_form) {
+  if (n == nullptr || (bn_mode != VEEX_BN_INFERENCE && bn_mode != VEEX_BN_BATCH) || (bce_form != VEEX_BCE_LOGITS && bce_form != VEEX_BCE_PROBS)) {
+    veex_set_error("set_semantics: bad arguments"); return VEEX_EINVAL;
+  }
+  if (bn_mode == VEEX_BN_BATCH && n->compute != VEEX_COMPUTE_F32) { veex_set_error("set_semantics: batch-statistics BatchNorm runs on the fp32 engine only"); return VEEX_EINVAL; }
+  n->bn_mode = bn_mode; n->bce_form = bce_form;
   return 0;
 }
 extern "C" int veex_net_set_batch_divisor(VeexNet* n, double divisor) {
@@ -772,8 +790,9 @@ static int decoder_trunk(Ctx& c, const float* z) {
 static int deconv6_forward(Ctx& c, const float* target, float* logits, float* recon, float* dlogit, float* rec_b,
                            float* dlsum_b) {
   const VeexNet* n = c.n;
-  return veex_deconv6_bce_fwd(c.ws + c.plan.act_dc[4], c.scale(n->dc[4].bn), c.shift(n->dc[4].bn), c.P + n->dc[5].w,
-                              c.P + n->dc[5].b, target, logits, recon, dlogit, rec_b, dlsum_b, c.B, c.inv_div(), c.st);
+  return veex_deconv6_bce_fwd_form(c.ws + c.plan.act_dc[4], c.scale(n->dc[4].bn), c.shift(n->dc[4].bn), c.P + n->dc[5].w,
+                                   c.P + n->dc[5].b, target, logits, recon, dlogit, rec_b, dlsum_b, c.B, c.inv_div(),
+                                   n->bce_form, c.st);
 }
 
 static hipEvent_t next_event(const VeexNet* n) {

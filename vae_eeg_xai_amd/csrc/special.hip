@@ -282,6 +282,9 @@ __global__ __launch_bounds__(256) void conv1_dgrad_kernel(const float* __restric
 // phase 2: per output pixel gather <=4 of them, BCE, dlogit = (sigmoid - t)/B, block reduction.
 // ---------------------------------------------------------------------------------------
 #define D6_THREADS 512
+// PROBS: the clipped-probability form of keras.backend.binary_crossentropy (SURVEY A.4's fallback, behind
+// veex_net_set_semantics) instead of the from-logits form the reference is read to take
+template <bool PROBS>
 __global__ __launch_bounds__(D6_THREADS) void deconv6_bce_fwd_kernel(
     const float* __restrict__ a5, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ W6, const float* __restrict__ b6, const float* __restrict__ target,
@@ -360,8 +363,17 @@ __global__ __launch_bounds__(D6_THREADS) void deconv6_bce_fwd_kernel(
     if (recon != nullptr) recon[oi] = sg;
     if (target != nullptr) {
       const float t = treg[k];
-      bce_sum += fmaxf(a, 0.f) - a * t + log1pf(e);
-      const float dl = (sg - t) * inv_batch;
+      float dl;
+      if (PROBS) {   // -(t log(p + 1e-7) + (1 - t) log(1 - p + 1e-7)), p = clip(sigmoid(a), 1e-7, 1 - 1e-7); no gradient through an active clip
+        const float ce = 1e-7f;
+        const float pr = fminf(fmaxf(sg, ce), 1.f - ce);
+        bce_sum -= t * logf(pr + ce) + (1.f - t) * logf(1.f - pr + ce);
+        const bool inside = sg >= ce && sg <= 1.f - ce;
+        dl = inside ? ((1.f - t) / (1.f - pr + ce) - t / (pr + ce)) * sg * (1.f - sg) * inv_batch : 0.f;
+      } else {
+        bce_sum += fmaxf(a, 0.f) - a * t + log1pf(e);
+        dl = (sg - t) * inv_batch;
+      }
       dl_sum += dl;
       if (dlogit != nullptr) dlogit[oi] = dl;
     }
@@ -875,13 +887,23 @@ int veex_conv1_dgrad(const float* dpre, const float* W, const float* mul, float*
   return 0;
 }
 
+int veex_deconv6_bce_fwd_form(const float* a5, const float* scale, const float* shift, const float* W6, const float* b6,
+                               const float* target, float* logits, float* recon, float* dlogit, float* rec_b,
+                               float* dlsum_b, int B, float inv_batch, int bce_form, hipStream_t st) {
+  if (bce_form != 0 && bce_form != 1) { veex_set_error("deconv6_bce_fwd: bce_form must be 0 (logits) or 1 (probabilities)"); return -1; }
+  if (bce_form == 1)
+    hipLaunchKernelGGL(deconv6_bce_fwd_kernel<true>, dim3(B), dim3(D6_THREADS), 0, st, a5, scale, shift, W6, b6, target, logits,
+                       recon, dlogit, rec_b, dlsum_b, inv_batch);
+  else
+    hipLaunchKernelGGL(deconv6_bce_fwd_kernel<false>, dim3(B), dim3(D6_THREADS), 0, st, a5, scale, shift, W6, b6, target, logits,
+                       recon, dlogit, rec_b, dlsum_b, inv_batch);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
 int veex_deconv6_bce_fwd(const float* a5, const float* scale, const float* shift, const float* W6, const float* b6,
                           const float* target, float* logits, float* recon, float* dlogit, float* rec_b,
                           float* dlsum_b, int B, float inv_batch, hipStream_t st) {
-  hipLaunchKernelGGL(deconv6_bce_fwd_kernel, dim3(B), dim3(D6_THREADS), 0, st, a5, scale, shift, W6, b6, target, logits,
-                     recon, dlogit, rec_b, dlsum_b, inv_batch);
-  VEEX_CHECK_LAUNCH();
-  return 0;
+  return veex_deconv6_bce_fwd_form(a5, scale, shift, W6, b6, target, logits, recon, dlogit, rec_b, dlsum_b, B, inv_batch, 0, st);
 }
 
 int veex_deconv6_bwd(const float* dlogit, const float* a5, const float* scale, const float* shift, const float* W6,

@@ -104,6 +104,18 @@ class Net:
         self.compute = compute
         self._drop_workspaces()     # the workspace plan (split-K slabs) depends on the kernel family
 
+    def set_semantics(self, bn: str = "inference", bce: str = "logits"):
+        """The two Keras 2.13 readings of models.py:152-160 that nothing in the reference tree can pin (SURVEY A.3 /
+        A.4), each one switch away from its alternative (include/veex.h veex_net_set_semantics).  Defaults = the
+        survey's reading: BatchNormalization on its moving statistics inside train_step, BCE from logits.
+        ``bn="batch"``: batch statistics + gradients through them + moving-statistics update (fp32 engine);
+        ``bce="probs"``: keras.backend.binary_crossentropy on the clipped probabilities."""
+        if bn not in ("inference", "batch") or bce not in ("logits", "probs"):
+            raise ValueError("bn: 'inference' | 'batch', bce: 'logits' | 'probs'")
+        check(lib.veex_net_set_semantics(self._h, 1 if bn == "batch" else 0, 1 if bce == "probs" else 0), "net_set_semantics")
+        self.semantics = {"bn": bn, "bce": bce}
+        self._drop_graphs()
+
     def set_overlap(self, on: bool):
         """Run the weight-gradient GEMMs of the backward pass on a second HIP stream, concurrently
         with the input-gradient chain (joined before train_fwd_bwd returns).  VEEX_OVERLAP=0 forces one stream
