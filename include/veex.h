@@ -172,6 +172,13 @@ int veex_deconv6_bwd_bf16(const float* dlogit, const float* a5, const float* sca
  * and written back for the backward pass. */
 int veex_reparam_kl_fwd(const float* mulv, float* eps, float* z, float* kl_b, int batch, int latent, int use_philox,
                         unsigned long long seed, unsigned long long first_sample, veexStream_t s);
+/* same; `counter` (nullable) is a DEVICE word that the kernel adds to first_sample when it runs: a launch captured
+ * into a HIP graph then draws fresh epsilon on every replay (veex_net_set_sample_counter).  veex_counter_add:
+ * counter[0] += inc on the stream (one thread; the step's "samples seen" bookkeeping inside a captured graph). */
+int veex_reparam_kl_fwd_ctr(const float* mulv, float* eps, float* z, float* kl_b, int batch, int latent, int use_philox,
+                            unsigned long long seed, unsigned long long first_sample,
+                            const unsigned long long* counter, veexStream_t s);
+int veex_counter_add(unsigned long long* counter, long long inc, veexStream_t s);
 int veex_reparam_kl_bwd(const float* dz, const float* mulv, const float* eps, float* dmulv, int batch, int latent,
                         float inv_batch, veexStream_t s);
 
@@ -282,6 +289,13 @@ int veex_net_set_semantics(VeexNet* net, int bn_mode, int bce_form);
  * creates nothing and can run under stream capture).
  * NULL (default) = everything on the one stream passed to the call. */
 int veex_net_set_side_stream(VeexNet* net, veexStream_t side);
+
+/* Optional device-side Philox sample counter (no reference call site: tf.random.normal is unseeded): when set, the
+ * whole-step entry points draw epsilon for sample index *device_counter + first_sample + b instead of
+ * first_sample + b, reading the word at RUN time -- so a train step captured into a HIP graph (a fixed small batch,
+ * where enqueueing ~60 launches costs the host more than the GPU needs to run them) replays with fresh epsilon.
+ * NULL (default) = first_sample by value only. */
+int veex_net_set_sample_counter(VeexNet* net, const unsigned long long* device_counter);
 
 /* Divisor of the batch-mean loss and of its gradients (models.py:156-163 reduce_mean over the batch).  0 (default):
  * the batch of the call.  Data parallelism with unequal shards sets global_batch / world on every rank, so that the

@@ -91,3 +91,33 @@ def test_train_py_shaped_driver(tmp_path):
     logs = vae2.test_step((x[:B], x[:B]), epsilon=eps)
     assert abs(logs["loss"] - c["total"]) < RTOL * abs(c["total"])
     assert abs(logs["kl_loss"] - c["kl_loss"]) < RTOL * max(abs(c["kl_loss"]), 1.0)
+
+
+@pytest.mark.parametrize("variant", ["vae", "ae"])
+def test_fit_from_a_captured_graph_equals_the_eager_fit(variant):
+    """VAE.fit replays full batches from a captured HIP graph (gather + train_fwd_bwd + Adam; the Philox sample
+    counter is read from a device word at run time): history and final weights are bit-identical to the eager
+    fit -- ragged last batch, validation between epochs and a change of the learning rate (new capture) included."""
+    import torch
+    if variant == "vae":
+        from vae_eeg_xai_amd.models import Encoder, Decoder, VAE as Model, Adam
+    else:
+        from vae_eeg_xai_amd.models_standard import (EncoderStandard as Encoder, DecoderStandard as Decoder,
+                                                     Autoencoder as Model, Adam)
+    N, NV, bs, L = 150, 40, 32, 28            # batches 32, 32, 32, 32, 22
+    p = vo.init_params(L, variant, seed=6, jitter=0.1)
+    x = vo.synth_topomaps(N + NV, 21)
+    out = []
+    for graph in (False, True):
+        model = Model(Encoder(L), Decoder())
+        model._net.set_weights_dict(p)
+        model.compile(Adam(1e-3))
+        h1 = model.fit(x[:N], x[:N], bs, 3, validation_data=(x[N:], x[N:]), verbose=0, seed=5, graph=graph)
+        model.compile(Adam(3e-4))
+        h2 = model.fit(x[:N], x[:N], bs, 2, verbose=0, seed=6, graph=graph)
+        torch.cuda.synchronize()
+        assert ("_train_graphs" in model._net.__dict__) == graph
+        out.append((h1.history, h2.history, model._net.params.clone(), model._net.adam_v.clone(), model._net.samples_seen))
+    (a1, a2, pa, va, sa), (b1, b2, pb, vb, sb) = out
+    assert a1 == b1 and a2 == b2 and sa == sb
+    assert torch.equal(pa, pb) and torch.equal(va, vb)

@@ -179,10 +179,12 @@ def test_probability_bce_is_the_logit_form_away_from_saturation_and_clips_at_it(
     a = np.array([-30.0, -17.0, -3.0, 0.0, 2.5, 17.0, 30.0])
     t = np.array([0.0, 0.3, 1.0, 0.5, 0.2, 1.0, 0.4])
     lo, pr = vo.bce_logits(a, t), vo.bce_probs(a, t)
-    assert np.allclose(lo[2:5], pr[2:5], rtol=0, atol=1e-6)          # "difference <~ 1e-7 except at saturation"
+    # the +1e-7 inside the logarithms shifts a term by ~1e-7 / p: 2e-6 at p = 0.05 -- the two forms differ at the
+    # 1e-6 .. 1e-5 level in loss and gradients (SURVEY A.4 says "<~ 1e-7"), i.e. right at the parity tolerance
+    assert np.allclose(lo[2:5], pr[2:5], rtol=0, atol=5e-6)
     assert abs(pr[0] - (-np.log(1 - 1e-7 + 1e-7))) < 1e-12 and abs(pr[6] - (-(0.4 * np.log(1.0) + 0.6 * np.log(2e-7)))) < 1e-7
     d = vo.bce_probs_dlogit(a, t)
-    assert d[0] == 0.0 and d[6] == 0.0 and d[3] != 0.0                # no gradient through an active clip
+    assert d[0] == 0.0 and d[6] == 0.0 and d[4] != 0.0                # no gradient through an active clip
 
 
 def test_batch_statistics_mode_updates_the_moving_statistics():

@@ -16,7 +16,7 @@ for label, macs, fn in rl.gemm_cases(B, True):
     row = []
     for dbg, name in ((0, "full"), (1, "no mfma"), (2, "no epilogue"), (4, "no staging"), (8, "no weight chunks"), (16, "no barriers"),
                       (3, "no mfma, no epilogue"), (7, "no mfma/epi/staging"), (15, "only barriers + tables"), (31, "launch + tables"),
-                      (25, "staging + epilogue only")):
+                      (25, "staging + epilogue only"), (63, "launch, no tables"), (64, "return at once")):
         _lib.setenv("VEEX_HG_DBG", dbg)
         row.append(f"{name}: {timed(fn):.1f}")
     print(label, " | ".join(row), flush=True)

@@ -42,9 +42,12 @@ int veex_env_int(const char* name, int dflt) {
   }
   return it->second.set ? it->second.v : dflt;
 }
+static int g_env_gen = 0;
+int veex_env_generation(void) { std::lock_guard<std::mutex> lk(g_env_mu); return g_env_gen; }   // bumps when the switches are re-read: cached plans are stale
 extern "C" void veexi_debug_reload_env(void) {
   std::lock_guard<std::mutex> lk(g_env_mu);
   g_env.clear();
+  ++g_env_gen;
 }
 extern "C" int veex_abi_version(void) { return VEEX_ABI_VERSION; }
 
@@ -187,6 +190,7 @@ struct VeexNet {
   int L, variant, H1;
   int compute;                  // VEEX_COMPUTE_F32 / VEEX_COMPUTE_BF16
   double batch_div = 0.0;       // divisor of the batch-mean loss; 0 = the batch of the call (veex_net_set_batch_divisor)
+  const unsigned long long* sample_counter = nullptr;   // optional device word added to first_sample (veex_net_set_sample_counter)
   int bn_mode = VEEX_BN_INFERENCE, bce_form = VEEX_BCE_LOGITS;   // the two unpinned Keras readings (veex_net_set_semantics)
   hipStream_t side = nullptr;   // optional caller-owned second stream for the weight-gradient GEMMs
   mutable hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -364,6 +368,11 @@ extern "C" int veex_net_set_semantics(VeexNet* n, int bn_mode, int bce_form) {
   }
   if (bn_mode == VEEX_BN_BATCH && n->compute != VEEX_COMPUTE_F32) { veex_set_error("set_semantics: batch-statistics BatchNorm runs on the fp32 engine only"); return VEEX_EINVAL; }
   n->bn_mode = bn_mode; n->bce_form = bce_form;
+  return 0;
+}
+extern "C" int veex_net_set_sample_counter(VeexNet* n, const unsigned long long* device_counter) {
+  if (n == nullptr) { veex_set_error("set_sample_counter: null net"); return VEEX_EINVAL; }
+  n->sample_counter = device_counter;
   return 0;
 }
 extern "C" int veex_net_set_batch_divisor(VeexNet* n, double divisor) {
@@ -986,8 +995,8 @@ static int encode_impl(Ctx& c, const float* x, float* eps_io, int flags, unsigne
         veex_set_error("epsilon copy failed"); return VEEX_ELAUNCH;
       }
     }
-    TRY(veex_reparam_kl_fwd(c.ws + P.mulv, eps, c.ws + P.z, want_kl ? c.ws + P.kl_b : nullptr, c.B, n->L, philox, seed,
-                            first_sample, c.st));
+    TRY(veex_reparam_kl_fwd_ctr(c.ws + P.mulv, eps, c.ws + P.z, want_kl ? c.ws + P.kl_b : nullptr, c.B, n->L, philox, seed,
+                                first_sample, philox ? n->sample_counter : nullptr, c.st));
     if (philox && eps_io != nullptr) {
       if (hipMemcpyAsync(eps_io, eps, sizeof(float) * (size_t)c.B * n->L, hipMemcpyDeviceToDevice, c.st) != hipSuccess) {
         veex_set_error("epsilon copy failed"); return VEEX_ELAUNCH;

@@ -498,7 +498,11 @@ __device__ __forceinline__ float philox_normal(unsigned long long e, unsigned k0
 __global__ __launch_bounds__(64) void reparam_kl_fwd_kernel(const float* __restrict__ mulv, float* __restrict__ eps,
                                                             float* __restrict__ z, float* __restrict__ kl_b, int L,
                                                             int use_philox, unsigned long long seed,
-                                                            unsigned long long first_sample) {
+                                                            unsigned long long first_sample,
+                                                            const unsigned long long* __restrict__ counter) {
+  // counter (nullable): a device word added to first_sample -- a captured graph replays with fresh epsilon because
+  // the Philox counter is READ at run time instead of being frozen into the launch (veex_net_set_sample_counter)
+  if (counter != nullptr) first_sample += counter[0];
   const int b = blockIdx.x;
   float kl = 0.f;
   for (int l = threadIdx.x; l < L; l += 64) {
@@ -920,10 +924,22 @@ int veex_deconv6_bwd_bf16(const float* dlogit, const float* a5, const float* sca
   return 0;
 }
 
+int veex_reparam_kl_fwd_ctr(const float* mulv, float* eps, float* z, float* kl_b, int B, int L, int use_philox,
+                             unsigned long long seed, unsigned long long first_sample, const unsigned long long* counter,
+                             hipStream_t st) {
+  hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3(B), dim3(64), 0, st, mulv, eps, z, kl_b, L, use_philox, seed,
+                     first_sample, counter);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
 int veex_reparam_kl_fwd(const float* mulv, float* eps, float* z, float* kl_b, int B, int L, int use_philox,
                          unsigned long long seed, unsigned long long first_sample, hipStream_t st) {
-  hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3(B), dim3(64), 0, st, mulv, eps, z, kl_b, L, use_philox, seed,
-                     first_sample);
+  return veex_reparam_kl_fwd_ctr(mulv, eps, z, kl_b, B, L, use_philox, seed, first_sample, nullptr, st);
+}
+__global__ void counter_add_kernel(unsigned long long* ctr, long long inc) { ctr[0] += (unsigned long long)inc; }
+int veex_counter_add(unsigned long long* counter, long long inc, hipStream_t st) {
+  if (counter == nullptr) { veex_set_error("counter_add: null counter"); return -1; }
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, st, counter, inc);
   VEEX_CHECK_LAUNCH();
   return 0;
 }

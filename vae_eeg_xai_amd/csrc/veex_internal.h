@@ -104,6 +104,7 @@ __device__ __forceinline__ void veex_block_coords(int remap, int gx, int gy, int
 }
 #endif
 
+int veex_env_generation(void);                  // changes whenever veexi_debug_reload_env() made the switches stale
 int veex_env_int(const char* name, int dflt);   // read once per process and frozen; veexi_debug_reload_env() re-reads
 
 // launchers (host side; enqueue only, no sync, no allocation)

@@ -432,12 +432,19 @@ class VAE:
             seed = vdist.broadcast_int(int(np.random.SeedSequence().entropy % (1 << 62)) if seed is None else int(seed))
         rng = np.random.default_rng(seed)
         self.stop_training = False
+        # the reference trains at batch 32-128 (train.py:104-109), where a step is bound by the host's ~60 enqueues:
+        # full batches are replayed from a captured HIP graph (Net.train_step_graphed; graph=False keeps it eager)
+        use_graph = bool(kwargs.get("graph", True)) and world == 1 and batch_size <= net.GRAPH_MAX_BATCH and N >= batch_size
         for epoch in range(int(epochs)):
             perm = rng.permutation(N) if shuffle else np.arange(N)
             perm_d = torch.from_numpy(perm).to(net.device)
             net.metrics.zero_()
             for s in range(0, N, batch_size):
-                self._step(xd, None, index=perm_d[s:s + batch_size])
+                idx = perm_d[s:s + batch_size]
+                if use_graph and idx.shape[0] == batch_size:
+                    net.train_step_graphed(xd, idx, self._lr())      # full batches: one graph replay per step
+                else:
+                    self._step(xd, None, index=idx)                  # ragged last batch, large batches, data parallel
             logs = self._logs()
             if xv is not None:
                 self._validate(xv, batch_size)

@@ -371,6 +371,63 @@ class Net:
         g.replay()
         return out
 
+    # ---------------- captured train step (small batches) ----------------
+    GRAPH_MAX_BATCH = 256        # above this the step is GPU-bound and eager enqueueing keeps up
+
+    def train_step_graphed(self, x_rows: torch.Tensor, index: torch.Tensor, lr: float):
+        """One whole optimisation step -- gather of the batch, veex_net_train_fwd_bwd, veex_adam -- replayed from a
+        HIP graph: at the reference's batch sizes (32-128, train.py:104-109) the ~60 launches of a step cost the host
+        more to enqueue through Python than the GPU needs to run them.  ``x_rows`` is the resident set, ``index``
+        (device int64, length B) the rows of this batch.  Captured once per (B, lr, set); the Philox epsilon of a
+        replay is fresh because the kernel reads the sample counter from a device word (veex_net_set_sample_counter)
+        that the graph itself advances by B; ``samples_seen`` on the host is advanced alongside, and the two are
+        re-aligned whenever an eager call moved the host count.  Same kernels, same order, same arithmetic as the
+        eager step: bit-identical results (tests/test_gpu_driver.py).  Single process only (no all-reduce inside)."""
+        B = int(index.shape[0])
+        graphs = self.__dict__.setdefault("_train_graphs", {})
+        ent = graphs.get(B)
+        key = (float(lr), x_rows.data_ptr(), tuple(x_rows.shape))
+        if ent is not None and ent["key"] != key:
+            ent = None
+        if ent is None:
+            ctr = torch.zeros(1, dtype=torch.int64, device=self.device)
+            sidx = torch.zeros(B, dtype=torch.int64, device=self.device)
+            sx = torch.empty(B, 40, 40, 1, dtype=torch.float32, device=self.device)
+            ws = self.workspace(B)
+            rows2d = x_rows.view(x_rows.shape[0], -1)
+
+            def body():
+                torch.index_select(rows2d, 0, sidx, out=sx.view(B, -1))
+                self.train_fwd_bwd(sx, None, accumulate_metrics=True, first_sample=0)
+                check(lib.veex_counter_add(C.c_void_p(ctr.data_ptr()), B, _lib.current_stream()), "counter_add")
+                self.adam_step(lr)
+
+            # warm-up off the default stream (function attributes, allocator) on a snapshot of everything a step
+            # changes, restored afterwards: the capture run itself executes nothing
+            snap = [t.clone() for t in (self.params, self.adam_m, self.adam_v, self.adam_step_count, self.metrics)]
+            check(lib.veex_net_set_sample_counter(self._h, C.c_void_p(ctr.data_ptr())), "set_sample_counter")
+            try:
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side):
+                    body()
+                torch.cuda.current_stream(self.device).wait_stream(side)
+                for t, s in zip((self.params, self.adam_m, self.adam_v, self.adam_step_count, self.metrics), snap):
+                    t.copy_(s)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    body()
+            finally:
+                check(lib.veex_net_set_sample_counter(self._h, None), "set_sample_counter")
+            ent = graphs[B] = {"g": g, "ctr": ctr, "idx": sidx, "x": sx, "ws": ws, "key": key, "rows": x_rows, "dev_count": None}
+        if ent["dev_count"] != self.samples_seen:          # an eager call (validation, a ragged batch) moved the count
+            ent["ctr"].fill_(self.samples_seen)
+        ent["idx"].copy_(index)
+        ent["g"].replay()
+        self.samples_seen += B
+        ent["dev_count"] = self.samples_seen
+        return self.grads[self.n_params:self.n_params + 3]
+
     def train_fwd_bwd(self, x, eps=None, accumulate_metrics=True, first_sample: Optional[int] = None):
         """Forward + loss + every gradient (VAE.train_step up to tape.gradient).  The three loss
         scalars land in grads[-4:-1]."""
