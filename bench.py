@@ -219,6 +219,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-attribution", action="store_true")
+    ap.add_argument("--buckets", type=int, choices=[1, 2], default=2,
+                    help="N > 1: 2 = decoder gradients all-reduced on a communication stream while the encoder's backward "
+                         "pass runs (dist.TwoBucketReducer), 1 = one all-reduce after the backward pass")
     ap.add_argument("--no-bf16", action="store_true", help="skip the bf16-engine leg (the `bf16` object of the JSON line)")
     args = ap.parse_args()
 
@@ -265,12 +268,17 @@ def main():
     nb = n_local // B
     note(f"{n_local} synthetic maps resident per rank")
 
+    red = vdist.TwoBucketReducer(net) if (world > 1 and args.buckets == 2) else None
+
     def step(i, exchange=True):
         xb = x_all[(i % nb) * B:(i % nb + 1) * B]
         # Philox epsilon keyed by the global sample index -> independent of the world size
         net.train_fwd_bwd(xb, None, first_sample=(i * world + rank) * B)
         if world > 1 and exchange:
-            vdist.allreduce_sum_(net.grads)        # one RCCL all-reduce: grads + 3 loss scalars
+            if red is not None:
+                red.reduce_()                      # decoder bucket behind its event on the comm stream, the rest here
+            else:
+                vdist.allreduce_sum_(net.grads)    # one RCCL all-reduce: grads + 3 loss scalars
         net.adam_step(LR, 1.0 / world)
 
     for i in range(args.warmup):
@@ -304,6 +312,8 @@ def main():
         torch.cuda.synchronize()
         local_ms = 1e3 * (time.perf_counter() - t1) / args.steps
         dist.barrier()
+    if red is not None:
+        red.close()
     attr = None if args.no_attribution else attribution_bench(net, x_all, world, L)
     bf16 = None
     if args.dtype == "f32" and not args.no_bf16:
@@ -332,6 +342,11 @@ def main():
         }
         if local_ms is not None:
             out["local_step_ms_without_allreduce"] = local_ms
+            out["allreduce_exposed_ms"] = out["ms_per_step"] - local_ms     # what the exchange adds to a step on this rank
+            out["config"]["grad_buckets"] = args.buckets
+            out["config"]["equal_work_single_gpu"] = (
+                f"local_step_ms_without_allreduce: the same {B}-sample step on one GPU with no exchange; the driver's N=1 "
+                f"line is configs[1] at batch {LOCAL_BATCH}/GPU and is NOT the equal-work denominator of this line")
         if attr is not None:
             out["attribution"] = attr
         if bf16 is not None:

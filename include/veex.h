@@ -290,6 +290,15 @@ int veex_net_set_semantics(VeexNet* net, int bn_mode, int bce_form);
  * NULL (default) = everything on the one stream passed to the call. */
 int veex_net_set_side_stream(VeexNet* net, veexStream_t side);
 
+/* Data parallelism in two buckets (no reference call site: the reference is single-process).  The gradients of the
+ * decoder's kernels and biases -- one contiguous range of the flat buffer, veex_net_grad_bucket -- are final long
+ * before veex_net_train_fwd_bwd's last kernel: with a caller-owned event set here, the call records it (on the side
+ * stream when there is one, else on the call's stream) at the point where that range is complete, so that the
+ * caller can start its all-reduce on a communication stream (hipStreamWaitEvent) while the encoder's backward pass
+ * still runs, and reduce the rest after the call.  The gradients are the same bits either way.  NULL = off. */
+int veex_net_set_bucket_event(VeexNet* net, void* hip_event);
+int veex_net_grad_bucket(const VeexNet* net, long long* first_float, long long* n_floats);
+
 /* Optional device-side Philox sample counter (no reference call site: tf.random.normal is unseeded): when set, the
  * whole-step entry points draw epsilon for sample index *device_counter + first_sample + b instead of
  * first_sample + b, reading the word at RUN time -- so a train step captured into a HIP graph (a fixed small batch,

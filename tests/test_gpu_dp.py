@@ -119,3 +119,55 @@ def test_rccl_backend_single_rank_fit_equals_the_plain_fit(tmp_path):
             assert np.allclose(dp[k], one[k], rtol=1e-6, atol=0), (k, dp[k], one[k])
         elif k.startswith("w."):
             assert np.abs(dp[k] - one[k]).max() <= 1e-6 * max(np.abs(one[k]).max(), 1e-3), k
+
+
+def test_bucket_event_changes_no_gradient_bit():
+    """veex_net_set_bucket_event: the early column-sum flush and the fork that records the event reorder nothing that
+    feeds a sum -- every gradient has the same bits with and without it; the event completes; the early bucket is the
+    decoder's kernels and biases."""
+    import torch
+    from vae_eeg_xai_amd.net import Net
+    L, B = 28, 96
+    p = vo.init_params(L, "vae", seed=6, jitter=0.1)
+    x = torch.from_numpy(vo.synth_topomaps(B, 8)).cuda()
+    eps = torch.randn(B, L, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    res = []
+    for variant in ("vae", "ae"):
+        for overlap in (True, False):
+            for use_event in (False, True):
+                net = Net(L, variant, overlap=overlap)
+                net.set_weights_dict({k: v for k, v in vo.init_params(L, variant, seed=6, jitter=0.1).items()})
+                ev = torch.cuda.Event()
+                if use_event:
+                    net.set_bucket_event(ev)
+                net.train_fwd_bwd(x, eps if variant == "vae" else None)
+                if use_event:
+                    ev.synchronize()
+                torch.cuda.synchronize()
+                res.append(net.grads.clone())
+                first, count = net.grad_bucket()
+                names = [s.name for s in net.specs if s.trainable and first <= s.offset < first + count]
+                assert names[0] == "dec.dense.kernel" and names[-1] == "dec.deconv6.bias" and len(names) == 14
+            assert torch.equal(res[-1], res[-2]), (variant, overlap)
+
+
+def test_two_bucket_exchange_equals_the_single_all_reduce(tmp_path):
+    """Two real ranks (gloo, one GPU): `VAE.fit` with the overlapped two-bucket gradient exchange (default) against
+    the single all-reduce (VEEX_GRAD_BUCKETS=1) -- history and every weight BITWISE equal (the same element-wise
+    sums over the same ranks), ragged batches and an empty-shard step included."""
+    n, batch, epochs, L, seed, n_val, lr = 67, 32, 2, 8, 5, 9, 1e-3     # last batch 3 samples -> shards 2 + 1
+    outs = []
+    for buckets in ("1", "2"):
+        out = os.path.join(tmp_path, f"dp_b{buckets}.npz")
+        env = dict(os.environ, VEEX_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", VEEX_GRAD_BUCKETS=buckets)
+        port = 29800 + os.getpid() % 1000 + int(buckets)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dp_worker.py"), out,
+               *map(str, (n, batch, epochs, L, seed, n_val, lr))]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    a, b = outs
+    assert set(a.files) == set(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k

@@ -78,6 +78,8 @@ SIGNATURES = {
     "veex_deconv6_bce_fwd_form": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _I, _P]),
     "veex_net_set_semantics": (_I, [_P, _I, _I]),
     "veex_net_set_sample_counter": (_I, [_P, _P]),
+    "veex_net_set_bucket_event": (_I, [_P, _P]),
+    "veex_net_grad_bucket": (_I, [_P, C.POINTER(_L), C.POINTER(_L)]),
     "veex_reparam_kl_fwd_ctr": (_I, [_P, _P, _P, _P, _I, _I, _I, _U, _U, _P, _P]),
     "veex_counter_add": (_I, [_P, _L, _P]),
     "veex_deconv6_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),

@@ -51,6 +51,7 @@ extern "C" void veexi_debug_reload_env(void) {
 }
 extern "C" int veex_abi_version(void) { return VEEX_ABI_VERSION; }
 
+extern "C" int veexi_deconv6_bwd_raw(const float*, const float*, const float*, const float*, const float*, float*, float*, int, hipStream_t);
 extern "C" int veexi_loss_finalize(const float*, const float*, const float*, int, double, float*, float*, float*, hipStream_t);
 extern "C" int veexi_attr_seed(const float*, const float*, float*, int, int, int, int, int, hipStream_t);
 
@@ -190,6 +191,7 @@ struct VeexNet {
   int L, variant, H1;
   int compute;                  // VEEX_COMPUTE_F32 / VEEX_COMPUTE_BF16
   double batch_div = 0.0;       // divisor of the batch-mean loss; 0 = the batch of the call (veex_net_set_batch_divisor)
+  hipEvent_t bucket_ev = nullptr;   // optional caller-owned event: "the decoder's gradients are final" (veex_net_set_bucket_event)
   const unsigned long long* sample_counter = nullptr;   // optional device word added to first_sample (veex_net_set_sample_counter)
   int bn_mode = VEEX_BN_INFERENCE, bce_form = VEEX_BCE_LOGITS;   // the two unpinned Keras readings (veex_net_set_semantics)
   hipStream_t side = nullptr;   // optional caller-owned second stream for the weight-gradient GEMMs
@@ -370,6 +372,17 @@ extern "C" int veex_net_set_semantics(VeexNet* n, int bn_mode, int bce_form) {
   n->bn_mode = bn_mode; n->bce_form = bce_form;
   return 0;
 }
+extern "C" int veex_net_set_bucket_event(VeexNet* n, void* event) {
+  if (n == nullptr) { veex_set_error("set_bucket_event: null net"); return VEEX_EINVAL; }
+  n->bucket_ev = static_cast<hipEvent_t>(event);
+  return 0;
+}
+extern "C" int veex_net_grad_bucket(const VeexNet* n, long long* first, long long* count) {
+  if (n == nullptr || first == nullptr || count == nullptr) { veex_set_error("grad_bucket: null argument"); return VEEX_EINVAL; }
+  *first = n->ddense.w;                      // dec.dense kernel ... dec.deconv6 bias: contiguous in the flat buffer
+  *count = n->gamma_off - n->ddense.w;
+  return 0;
+}
 extern "C" int veex_net_set_sample_counter(VeexNet* n, const unsigned long long* device_counter) {
   if (n == nullptr) { veex_set_error("set_sample_counter: null net"); return VEEX_EINVAL; }
   n->sample_counter = device_counter;
@@ -466,7 +479,7 @@ static int gg_split(int mtiles, int Cout, int chunks) {
 
 struct Plan {
   Ws ws;
-  long long bn_scale, bn_shift, bn_rstd;
+  long long bn_scale, bn_shift, bn_rstd, bn_mu, bn_coef, bn_scratch;
   long long act_conv[3], act_h, mulv, eps, z;
   long long act_dd, act_dc[5], dlogit, rec_b, kl_b, dlsum_b;
   long long d_conv[3], d_h, dmulv, dz, d_dd, g_dd, d_dc[5];
@@ -514,6 +527,16 @@ static void make_plan(const VeexNet* n, int B, Plan& P) {
   P.bn_scale = w.add("bn.scale", n->n_bn);
   P.bn_shift = w.add("bn.shift", n->n_bn);
   P.bn_rstd = w.add("bn.rstd", n->n_bn);
+  P.bn_mu = w.add("bn.mu", n->n_bn);                     // batch means (VEEX_BN_BATCH)
+  P.bn_coef = w.add("bn.coef", 3LL * 4096);              // backward coefficients of one layer (largest: dec.dense)
+  {
+    long long d = 0;
+    auto upd2 = [&](long long rows, int C) { const long long v = veex_bn_batch_scratch_doubles(rows, C); if (v > d) d = v; };
+    for (int i = 0; i < 3; ++i) upd2((long long)B * n->conv[i].Hout * n->conv[i].Hout, n->conv[i].Cout);
+    upd2(B, 4096);
+    for (int i = 0; i < 5; ++i) upd2((long long)B * n->dc[i].Hout * n->dc[i].Hout, n->dc[i].Cout);
+    P.bn_scratch = w.add("bn.scratch", 2 * d);           // doubles, as floats
+  }
   for (int i = 0; i < 3; ++i) P.act_conv[i] = w.add(std::string("act.") + n->conv[i].name, act_floats(n->conv[i], B));
   P.act_h = w.add("act.enc.dense", (long long)B * H1);
   if (n->variant == VEEX_VARIANT_VAE) {
@@ -635,6 +658,7 @@ struct Ctx {
   hipStream_t st;
   long long part_cur = 0;       // bump cursor into scratch.partials: every producer of one pass keeps its own rows
   ColsumBatch fin;              // column-sum finalisations collected during the backward pass (flush_colsum)
+  bool batch_bn = false;        // this call normalises with batch statistics (train_fwd_bwd under VEEX_BN_BATCH)
   bool have_wt_enc = false, have_wt_bwd = false;   // packed fp32 weight copies made by this call (run_transpose_weights)
   // divisor of the batch mean (models.py:156-163): the local batch, or the caller's (a rank's share of a global batch)
   double div() const { return (n->batch_div > 0.0) ? n->batch_div : (double)B; }
@@ -642,7 +666,7 @@ struct Ctx {
   const float* scale(int bn) const { return ws + plan.bn_scale + bn; }
   const float* shift(int bn) const { return ws + plan.bn_shift + bn; }
   const float* rstd(int bn) const { return ws + plan.bn_rstd + bn; }
-  const float* mean(int bn) const { return S + bn; }
+  const float* mean(int bn) const { return batch_bn ? ws + plan.bn_mu + bn : S + bn; }
 };
 
 static int check_common(const VeexNet* n, const void* params, const void* state, int B, const float* ws,
@@ -704,7 +728,27 @@ static const void* packed_w(const Ctx& c, int i, int fwd) {
 // pointer to a bf16 consumer copy region (nullptr in fp32 mode)
 static void* bfp(const Ctx& c, long long off) { return (off < 0) ? nullptr : static_cast<void*>(c.ws + off); }
 // pointer to a BatchNorm-applied fp32 copy (nullptr in bf16 mode, or with VEEX_BNCOPY=0: consumers then apply the affine)
-static float* bnp(const Ctx& c, long long off) { return (off < 0 || !veex_env_int("VEEX_BNCOPY", 1)) ? nullptr : c.ws + off; }
+// (nor with batch statistics: a producer cannot apply a normalisation whose statistics are its own output's)
+static float* bnp(const Ctx& c, long long off) { return (off < 0 || c.batch_bn || !veex_env_int("VEEX_BNCOPY", 1)) ? nullptr : c.ws + off; }
+
+// VEEX_BN_BATCH: statistics of layer l's activation -> its scale / shift / rstd / mean slots, moving statistics updated
+static int bn_batch_forward(Ctx& c, const ConvLayer& l, const float* act) {
+  const VeexNet* n = c.n;
+  const long long rows = (long long)c.B * l.Hout * l.Hout * l.Cout / l.bnC;   // dec.dense: Hout = 1, bnC = 4096 -> B rows
+  float* S = const_cast<float*>(c.S);   // documented: veex_net_train_fwd_bwd writes the state buffer in this mode
+  return veex_bn_batch_forward(act, rows, l.bnC, c.P + n->gamma_off + l.bn, c.P + n->beta_off + l.bn, BN_EPS, 0.99f,
+                               /*unbiased=*/l.Hout > 1 || l.k > 1, c.ws + c.plan.bn_scale + l.bn, c.ws + c.plan.bn_shift + l.bn,
+                               c.ws + c.plan.bn_rstd + l.bn, c.ws + c.plan.bn_mu + l.bn, S + l.bn, S + n->n_bn + l.bn,
+                               reinterpret_cast<double*>(c.ws + c.plan.bn_scratch), c.st);
+}
+// VEEX_BN_BATCH: v = dL/d(BatchNorm output of layer l) -> dpre (may alias v) + dgamma / dbeta / dbias of layer l
+static int bn_batch_backward(Ctx& c, const ConvLayer& l, const float* v, const float* act, float* dpre, float* G) {
+  const VeexNet* n = c.n;
+  const long long rows = (long long)c.B * l.Hout * l.Hout * l.Cout / l.bnC;
+  return veex_bn_batch_backward(v, act, rows, l.bnC, c.P + n->gamma_off + l.bn, c.ws + c.plan.bn_mu + l.bn,
+                                c.ws + c.plan.bn_rstd + l.bn, dpre, G + n->gamma_off + l.bn, G + n->beta_off + l.bn, G + l.b,
+                                c.ws + c.plan.bn_coef, reinterpret_cast<double*>(c.ws + c.plan.bn_scratch), c.st);
+}
 
 static int run_bn_prepare(Ctx& c) {
   TRY(run_pack_weights(c));
@@ -734,6 +778,7 @@ static int fwd_gemm(Ctx& c, const ConvLayer& l, int mode, const float* in, int i
     if (hipEventRecord(c.n->probe_ev[1], c.st) != hipSuccess) { veex_set_error("probe: event record failed"); return VEEX_ELAUNCH; }
     c.n->probe_state = 2;
   }
+  if (rc == 0 && c.batch_bn && l.bn >= 0) return bn_batch_forward(c, l, out);
   return rc;
 }
 
@@ -743,6 +788,7 @@ static int encoder_forward(Ctx& c, const float* x) {
   float* ws = c.ws;
   TRY(veex_conv1_fwd_copies(x, c.P + n->conv[0].w, c.P + n->conv[0].b, ws + P.act_conv[0], c.scale(n->conv[0].bn),
                             c.shift(n->conv[0].bn), bnp(c, P.bn_conv[0]), bfp(c, P.bf_act_conv[0]), c.B, c.st));
+  if (c.batch_bn) TRY(bn_batch_forward(c, n->conv[0], ws + P.act_conv[0]));
   TRY(fwd_gemm(c, n->conv[1], 0, ws + P.act_conv[0], n->conv[0].bn, 64, 0, ws + P.act_conv[1], 1, packed_w(c, 0, 1),
                bfp(c, P.bf_act_conv[0]), bfp(c, P.bf_act_conv[1]), packed_wt(c, 0), bnp(c, P.bn_conv[0]), bnp(c, P.bn_conv[1])));
   TRY(fwd_gemm(c, n->conv[2], 0, ws + P.act_conv[1], n->conv[1].bn, 128, 0, ws + P.act_conv[2], 1, packed_w(c, 1, 1),
@@ -912,6 +958,13 @@ static int flush_colsum(Ctx& c) {
 static int dgrad_bwd(Ctx& c, GGParams& p, const ConvLayer& prod, const float* aux, float* dpre, float* G, int want_param_grads,
                      bool f32_unused = false) {
   const VeexNet* n = c.n;
+  if (c.batch_bn && prod.bn >= 0 && want_param_grads) {
+    // batch statistics: the gradient wrt the BatchNorm output first (plain epilogue), then the backward through the
+    // statistics, which needs the complete column sums before it can form a single element
+    p.Out = dpre; p.epi = VEEX_EPI_FWD; p.relu = 0; p.bias = nullptr; p.nsplit = 1;
+    TRY(veex_launch_gather_gemm(p, c.st));
+    return bn_batch_backward(c, prod, dpre, aux, dpre, G);
+  }
   p.Out = dpre; p.aux = aux; p.epi = VEEX_EPI_BWD; p.relu = 1; p.nsplit = 1;
   if (prod.bn >= 0) { p.e_scale = c.scale(prod.bn); p.epi_cmask = prod.bnC - 1; }
   if (f32_unused && veex_gg_bf16_only(p) == 2) p.Out = nullptr;   // only the bf16 copy of this gradient is read
@@ -1079,6 +1132,8 @@ extern "C" int veex_net_train_fwd_bwd(const VeexNet* n, const float* params, con
   const Plan& P = c.plan;
   const int L = n->L, H1 = n->H1;
   const bool vae = (n->variant == VEEX_VARIANT_VAE);
+  c.batch_bn = (n->bn_mode == VEEX_BN_BATCH);     // (encode / decode / forward / attribute keep the moving statistics)
+  if (c.batch_bn && B < 2) { veex_set_error("train_fwd_bwd: batch-statistics BatchNorm needs a batch of at least 2"); return VEEX_EINVAL; }
 
   // ---- forward (models.py:152-163) ----
   TRY(run_bn_prepare(c));
@@ -1095,11 +1150,18 @@ extern "C" int veex_net_train_fwd_bwd(const VeexNet* n, const float* params, con
     float* d6 = take_partials(c, (long long)B * 448);   // rows 0-3 dW6 partials, rows 4-6 the three column sums
     if (d6 == nullptr) return VEEX_ENOMEM;
     float* d5 = (bfp(c, P.bf_d_dc[4]) != nullptr && dpre_dc_f32_unused(c, 4)) ? nullptr : ws + P.d_dc[4];
+    if (c.batch_bn) {
+      TRY(veexi_deconv6_bwd_raw(ws + P.dlogit, ws + P.act_dc[4], c.scale(l5.bn), c.shift(l5.bn), c.P + n->dc[5].w,
+                                ws + P.d_dc[4], d6, B, st));
+      TRY(veex_slab_sum(d6, B, 448, 256, G + n->dc[5].w, nullptr, 1, 0, st));
+      TRY(bn_batch_backward(c, l5, ws + P.d_dc[4], ws + P.act_dc[4], ws + P.d_dc[4], G));
+    } else {
     TRY(veex_deconv6_bwd_bf16(ws + P.dlogit, ws + P.act_dc[4], c.scale(l5.bn), c.shift(l5.bn), c.P + n->dc[5].w,
                               d5, bfp(c, P.bf_d_dc[4]), d6, B, st));
     TRY(veex_slab_sum(d6, B, 448, 256, G + n->dc[5].w, nullptr, 1, 0, st));
     TRY(defer_colsum(c, d6 + 256, B, 448, 64, 64, c.scale(l5.bn), c.mean(l5.bn), c.rstd(l5.bn), G + l5.b,
                      G + n->gamma_off + l5.bn, G + n->beta_off + l5.bn));
+    }
   }
   for (int i = 4; i >= 0; --i) {
     const ConvLayer& l = n->dc[i];
@@ -1115,6 +1177,7 @@ extern "C" int veex_net_train_fwd_bwd(const VeexNet* n, const float* params, con
       // BatchNorm of dec.dense runs over the flattened 4096 features: plain dgrad, then row-wise BN/ReLU backward
       p.Out = ws + P.g_dd; p.epi = VEEX_EPI_FWD; p.relu = 0; p.bias = nullptr; p.nsplit = 1;
       TRY(veex_launch_gather_gemm(p, st));
+      if (c.batch_bn) { TRY(bn_batch_backward(c, prod, ws + P.g_dd, ws + P.act_dd, ws + P.d_dd, G)); continue; }
       const int chunks = veex_bnrelu_bwd_rows_chunks(B);
       float* part = take_partials(c, (long long)chunks * 3 * 4096);
       if (part == nullptr) return VEEX_ENOMEM;
@@ -1140,6 +1203,15 @@ extern "C" int veex_net_train_fwd_bwd(const VeexNet* n, const float* params, con
     if ((long long)p.nsplit * p.slab_stride > P.slab_n) { veex_set_error("internal: slab scratch too small (dz)"); return VEEX_ENOMEM; }
     TRY(veex_launch_gather_gemm(p, st));
     TRY(veex_slab_sum(ws + P.slab, p.nsplit, p.slab_stride, p.slab_stride, ws + P.dz, nullptr, 1, 0, st));
+  }
+  if (n->bucket_ev != nullptr) {
+    // Data parallelism, early bucket: every kernel / bias gradient of the decoder (veex_net_grad_bucket) is final once
+    // the column sums collected so far are finalised and the weight-gradient GEMMs enqueued so far on the side stream
+    // have run.  The event is recorded on the side stream behind a fork from here, so the main stream does not wait.
+    TRY(flush_colsum(c));
+    hipStream_t es = st;
+    if (c.side != nullptr) { TRY(fork_side(c)); es = c.side; }
+    if (hipEventRecord(n->bucket_ev, es) != hipSuccess) { veex_set_error("bucket event record failed"); return VEEX_ELAUNCH; }
   }
   if (vae) {
     TRY(veex_reparam_kl_bwd(ws + P.dz, ws + P.mulv, ws + P.eps, ws + P.dmulv, B, L, c.inv_div(), st));

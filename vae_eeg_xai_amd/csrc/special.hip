@@ -398,7 +398,8 @@ __global__ __launch_bounds__(D6_THREADS) void deconv6_bce_fwd_kernel(
 __global__ __launch_bounds__(D6_THREADS) void deconv6_bwd_kernel(
     const float* __restrict__ dlogit, const float* __restrict__ a5, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ W6, float* __restrict__ dpre5,
-    float* __restrict__ slab, __bf16* __restrict__ dpre5_bf) {
+    float* __restrict__ slab, __bf16* __restrict__ dpre5_bf, int raw) {
+  // raw != 0 (batch-statistics BatchNorm, bn_batch.hip): dpre5 receives g = dL/d y5 itself -- no ReLU mask, no scale
   __shared__ __attribute__((aligned(16))) float dl[IMG * IMG];
   __shared__ __attribute__((aligned(16))) float red[(D6_THREADS / 16) * 7 * NCH];
   const int n = blockIdx.x;
@@ -451,6 +452,7 @@ __global__ __launch_bounds__(D6_THREADS) void deconv6_bwd_kernel(
     o.z = (a.z > 0.f) ? g.z : 0.f; o.w = (a.w > 0.f) ? g.w : 0.f;
     acc[6].x += o.x; acc[6].y += o.y; acc[6].z += o.z; acc[6].w += o.w;
     o.x *= sc.x; o.y *= sc.y; o.z *= sc.z; o.w *= sc.w;
+    if (raw) o = g;
     if (dpre5 != nullptr) *reinterpret_cast<float4*>(dst + pix * NCH + 4 * cq) = o;
     if (dpre5_bf != nullptr) {
       bf16x4_t h;
@@ -919,7 +921,15 @@ int veex_deconv6_bwd_bf16(const float* dlogit, const float* a5, const float* sca
                           float* dpre5, void* dpre5_bf16, float* slab, int B, hipStream_t st) {
   if (dpre5 == nullptr && dpre5_bf16 == nullptr) { veex_set_error("deconv6_bwd: no output buffer"); return -1; }
   hipLaunchKernelGGL(deconv6_bwd_kernel, dim3(B), dim3(D6_THREADS), 0, st, dlogit, a5, scale, shift, W6, dpre5, slab,
-                     reinterpret_cast<__bf16*>(dpre5_bf16));
+                     reinterpret_cast<__bf16*>(dpre5_bf16), 0);
+  VEEX_CHECK_LAUNCH();
+  return 0;
+}
+// internal (batch-statistics BatchNorm): dL/d y5 itself into g5, dW6 partials into slab rows 0-3 as usual
+int veexi_deconv6_bwd_raw(const float* dlogit, const float* a5, const float* scale, const float* shift, const float* W6,
+                          float* g5, float* slab, int B, hipStream_t st) {
+  hipLaunchKernelGGL(deconv6_bwd_kernel, dim3(B), dim3(D6_THREADS), 0, st, dlogit, a5, scale, shift, W6, g5, slab,
+                     static_cast<__bf16*>(nullptr), 1);
   VEEX_CHECK_LAUNCH();
   return 0;
 }

@@ -147,6 +147,15 @@ extern "C" int veex_pack_weights_bf16(const float* src, void* dst, int taps, int
 int veex_transpose_weights_f32_multi(int n, const float* const* src, float* const* dst, const int* taps, const int* rows,
                                      const int* cols, hipStream_t st);
 
+// bn_batch.hip: BatchNormalization on batch statistics (veex_net_set_semantics, VEEX_BN_BATCH)
+long long veex_bn_batch_scratch_doubles(long long rows, int C);
+int veex_bn_batch_forward(const float* act, long long rows, int C, const float* gamma, const float* beta, float eps, float momentum,
+                          int unbiased, float* scale, float* shift, float* rstd, float* mu, float* moving_mean, float* moving_var,
+                          double* scratch, hipStream_t st);
+int veex_bn_batch_backward(const float* v, const float* a, long long rows, int C, const float* gamma, const float* mu,
+                           const float* rstd, float* out, float* dgamma, float* dbeta, float* dbias, float* coef, double* scratch,
+                           hipStream_t st);
+
 void veex_set_error(const char* fmt, ...);
 
 #define VEEX_CHECK_LAUNCH()                                        \

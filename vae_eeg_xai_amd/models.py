@@ -289,6 +289,7 @@ class VAE:
         decoder._bind(self._net)
         self.optimizer = None
         self.stop_training = False
+        self.grad_buckets = int(kwargs.pop("grad_buckets", 2))   # data parallelism: 2 = overlapped exchange, 1 = one all-reduce
         self.total_loss_tracker = _Mean("total_loss", self, 0)
         self.reconstruction_loss_tracker = _Mean("reconstruction_loss", self, 1)
         self.kl_loss_tracker = _Mean("kl_loss", self, 2)
@@ -345,16 +346,35 @@ class VAE:
         included.  With one process this is the plain step."""
         net = self._net
         world, rank = vdist.world_size(), vdist.rank()
-        self._shard_fwd_bwd(x, epsilon, index, world, rank)
+        red = self._reducer(world)
+        ran = self._shard_fwd_bwd(x, epsilon, index, world, rank)
         if world > 1:
-            vdist.allreduce_sum_(net.grads)            # gradients and the 3 loss scalars in one collective
+            if red is not None:
+                red.reduce_(ran)                       # decoder bucket overlapped with the encoder's backward pass
+            else:
+                vdist.allreduce_sum_(net.grads)        # gradients and the 3 loss scalars in one collective
             net.metrics[:3] += net.grads[net.n_params:net.n_params + 3] / world
             net.metrics[3] += 1.0
         net.adam_step(self._lr(), 1.0 / world)
 
+    def _reducer(self, world):
+        """The two-bucket gradient exchange (dist.TwoBucketReducer) of a data-parallel run, or None: one process, or
+        ``grad_buckets=1`` / VEEX_GRAD_BUCKETS=1 (the single all-reduce, kept as the tested reference)."""
+        import os
+        want = int(os.environ.get("VEEX_GRAD_BUCKETS", getattr(self, "grad_buckets", 2)))
+        if world == 1 or want < 2:
+            if getattr(self, "_red", None) is not None:
+                self._red.close()
+                self._red = None
+            return None
+        if getattr(self, "_red", None) is None:
+            self._red = vdist.TwoBucketReducer(self._net)
+        return self._red
+
     def _shard_fwd_bwd(self, x, epsilon, index, world, rank):
         """Rank ``rank``'s share of one global step: its slice of the batch through
-        veex_net_train_fwd_bwd, gradients (already divided for the GLOBAL mean) into ``net.grads``."""
+        veex_net_train_fwd_bwd, gradients (already divided for the GLOBAL mean) into ``net.grads``.  Returns
+        whether a backward pass ran (False: an empty shard, the buffer was zeroed)."""
         net = self._net
         n_global = int(index.shape[0]) if index is not None else int(x.shape[0])
         lo, hi = vdist.shard_range(n_global, rank, world)
@@ -363,10 +383,10 @@ class VAE:
         if world == 1:
             xb = x if index is None else x.index_select(0, index)
             net.train_fwd_bwd(xb, epsilon, accumulate_metrics=True, first_sample=first)
-            return
+            return True
         if hi == lo:
             net.grads.zero_()                          # more ranks than samples: contribute nothing, still reduce
-            return
+            return False
         xb = x[lo:hi] if index is None else x.index_select(0, index[lo:hi])
         eb = None if epsilon is None else epsilon[lo:hi]
         net.set_batch_divisor(n_global / world)
@@ -374,6 +394,7 @@ class VAE:
             net.train_fwd_bwd(xb, eb, accumulate_metrics=False, first_sample=first)
         finally:
             net.set_batch_divisor(0.0)
+        return True
 
     def _validate(self, xv, batch_size):
         """test_step over the validation set (models.py:182-207), sharded like the training batches; the
@@ -432,9 +453,15 @@ class VAE:
             seed = vdist.broadcast_int(int(np.random.SeedSequence().entropy % (1 << 62)) if seed is None else int(seed))
         rng = np.random.default_rng(seed)
         self.stop_training = False
-        # the reference trains at batch 32-128 (train.py:104-109), where a step is bound by the host's ~60 enqueues:
-        # full batches are replayed from a captured HIP graph (Net.train_step_graphed; graph=False keeps it eager)
-        use_graph = bool(kwargs.get("graph", True)) and world == 1 and batch_size <= net.GRAPH_MAX_BATCH and N >= batch_size
+        # Full batches can be replayed from a captured HIP graph (Net.train_step_graphed: gather + train_fwd_bwd + Adam,
+        # bit-identical to the eager step).  Measured (profiles/r03_fit_batches.jsonl): at the reference's batch sizes
+        # (32-128, train.py:104-109) the step is NOT bound by the host's enqueues but by the GPU-side chain of its ~60
+        # dependent launches, which a graph replays one after the other just the same -- eager is 10-17 % faster there;
+        # the graph wins (6 %) around batch 256, where the host starts to fall behind.  graph=True / False forces it.
+        graph = kwargs.get("graph", None)
+        if graph is None:
+            graph = net.GRAPH_MIN_BATCH <= batch_size <= net.GRAPH_MAX_BATCH
+        use_graph = bool(graph) and world == 1 and N >= batch_size
         for epoch in range(int(epochs)):
             perm = rng.permutation(N) if shuffle else np.arange(N)
             perm_d = torch.from_numpy(perm).to(net.device)

@@ -207,6 +207,22 @@ class Net:
             if shp != tuple(s.shape):
                 raise ValueError(f"{s.name}: shape {shp} != {s.shape}")
 
+    def set_bucket_event(self, event: Optional["torch.cuda.Event"]):
+        """Data parallelism in two buckets (veex_net_set_bucket_event): train_fwd_bwd records ``event`` where the
+        decoder's kernel / bias gradients -- ``grad_bucket()``, one contiguous range of ``grads`` -- are final."""
+        if event is not None:
+            event.record()                      # materialises the HIP event (torch creates it lazily)
+        self._bucket_event = event
+        check(lib.veex_net_set_bucket_event(self._h, C.c_void_p(event.cuda_event) if event is not None else None),
+              "net_set_bucket_event")
+        self._drop_graphs()
+
+    def grad_bucket(self):
+        """(first, count) of the early gradient bucket inside ``grads``."""
+        first, count = C.c_longlong(), C.c_longlong()
+        check(lib.veex_net_grad_bucket(self._h, C.byref(first), C.byref(count)), "net_grad_bucket")
+        return first.value, count.value
+
     def set_batch_divisor(self, divisor: float = 0.0):
         """Divisor of the batch-mean loss and its gradients; 0 = the batch of the call.  A rank that holds
         ``n_local`` of ``n_global`` samples sets ``n_global / world``: SUM all-reduce + Adam's 1/world is
@@ -372,7 +388,7 @@ class Net:
         return out
 
     # ---------------- captured train step (small batches) ----------------
-    GRAPH_MAX_BATCH = 256        # above this the step is GPU-bound and eager enqueueing keeps up
+    GRAPH_MIN_BATCH, GRAPH_MAX_BATCH = 192, 384     # VAE.fit's automatic window (measured, profiles/r03_fit_batches.jsonl)
 
     def train_step_graphed(self, x_rows: torch.Tensor, index: torch.Tensor, lr: float):
         """One whole optimisation step -- gather of the batch, veex_net_train_fwd_bwd, veex_adam -- replayed from a

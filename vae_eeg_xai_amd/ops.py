@@ -37,7 +37,8 @@ def _h(net: int):
 
 
 # ------------------------------------------------------------------ whole-step ops
-@torch.library.custom_op("veex::train_fwd_bwd", mutates_args=("ws", "grads", "metrics", "eps"), device_types=_CUDA)
+# (state: written only under set_semantics(bn="batch"), which updates the BatchNorm moving statistics)
+@torch.library.custom_op("veex::train_fwd_bwd", mutates_args=("ws", "grads", "metrics", "eps", "state"), device_types=_CUDA)
 def train_fwd_bwd(net: int, params: Tensor, state: Tensor, x: Tensor, eps: Optional[Tensor], flags: int, seed: int,
                   first_sample: int, ws: Tensor, grads: Tensor, metrics: Optional[Tensor]) -> None:
     """VAE.train_step up to tape.gradient (models.py:148-166): all gradients into ``grads[:n_params]``,
