@@ -118,8 +118,10 @@ def losses(p, x, eps=None, variant="vae", masks=None, acts=None, sem=None):
     else:
         z = zm
     logits = decoder(p, z, masks, acts, sem)
-    if sem["bce"] == "probs":      # clipped-probability form; torch.clamp passes no gradient outside its range, like TF
-        pr = torch.clamp(torch.sigmoid(logits), vo.BCE_CLIP, 1.0 - vo.BCE_CLIP)
+    if sem["bce"] == "probs":
+        raise ValueError('torch_ref evaluates in float64: ask for bce="probs64" (vae_oracle.bce_probs, f32=False)')
+    if sem["bce"] == "probs64":    # clipped-probability form; torch.clamp passes no gradient outside its range, like TF
+        pr = torch.clamp(torch.sigmoid(logits), vo.BCE_CLIP, vo.BCE_CLIP_HI)
         bce = -(x * torch.log(pr + vo.BCE_CLIP) + (1.0 - x) * torch.log(1.0 - pr + vo.BCE_CLIP))
     else:
         bce = torch.clamp(logits, min=0) - logits * x + torch.log1p(torch.exp(-logits.abs()))

@@ -14,7 +14,11 @@ import numpy as np
 
 BN_EPS = 1e-3          # keras BatchNormalization default epsilon [KERAS-SEM]
 BN_MOMENTUM = 0.99     # keras BatchNormalization default momentum [KERAS-SEM]
-BCE_CLIP = 1e-7        # keras.backend.epsilon(): clip and log offset of the probability-form BCE [KERAS-SEM]
+# keras.backend.epsilon(): clip and log offset of the probability-form BCE [KERAS-SEM].  Keras evaluates that form in
+# float32, where the upper clip 1 - 1e-7 is not representable and rounds to 1 - 2**-23 = 1 - 1.19e-7: a saturated pixel
+# costs -log(2.19e-7) = 15.33, not -log(2e-7) = 15.42, so the constants are restated as float32 holds them.
+BCE_CLIP = float(np.float32(1e-7))
+BCE_CLIP_HI = float(np.float32(1.0) - np.float32(1e-7))
 
 # The two Keras semantics of the path that nothing in /root/reference can pin (SURVEY 7 "Hard parts", A.3, A.4), each
 # with its alternative one switch away.  The DEFAULT is what the survey reads out of Keras 2.13 for models.py:
@@ -26,7 +30,7 @@ BCE_CLIP = 1e-7        # keras.backend.epsilon(): clip and log offset of the pro
 #         tf.nn.sigmoid_cross_entropy_with_logits; "probs": the fallback on the clipped probabilities,
 #         -(t*log(p+1e-7) + (1-t)*log(1-p+1e-7)) with p = clip(sigmoid(a), 1e-7, 1-1e-7).
 DEFAULT_SEM = {"bn": "inference", "bce": "logits"}
-SEM_CHOICES = {"bn": ("inference", "batch"), "bce": ("logits", "probs")}
+SEM_CHOICES = {"bn": ("inference", "batch"), "bce": ("logits", "probs", "probs64")}
 
 
 def resolve_sem(sem=None):
@@ -317,19 +321,51 @@ def _bn_back(c, p, prefix, a, dy, sem):
     return bn_bwd_batch(a, p[prefix + ".gamma"], c[prefix + ".bn_mu"], c[prefix + ".bn_var"], dy)
 
 
-def bce_probs(a, t):
-    """keras.backend.binary_crossentropy on probabilities [KERAS-SEM] (the fallback form)."""
-    pr = np.clip(sigmoid(a), BCE_CLIP, 1.0 - BCE_CLIP)
-    return -(t * np.log(pr + BCE_CLIP) + (1.0 - t) * np.log(1.0 - pr + BCE_CLIP))
+def _sigmoid_f32(a):
+    a = np.asarray(a, dtype=np.float32)
+    e = np.exp(-np.abs(a))
+    one = np.float32(1.0)
+    return np.where(a >= 0, one / (one + e), e / (one + e)).astype(np.float32)
 
 
-def bce_probs_dlogit(a, t):
+def bce_probs(a, t, f32=True):
+    """keras.backend.binary_crossentropy on probabilities [KERAS-SEM] (the fallback form).
+
+    Keras evaluates this form in float32 and the form is NOT continuous there: sigmoid saturates to exactly 1 at
+    a > 16.6, 1 - p is a multiple of 2**-24, and the clip cuts at 1 - 2**-23.  A float64 evaluation is a different
+    function of the logits wherever |a| > ~12 (the gradient jumps from 0.54 to 0 across the clip edge), so the
+    restatement follows the float32 arithmetic (``f32=True``, what sem "probs" uses); ``f32=False`` ("probs64") is the
+    same formula in real arithmetic, for the finite-difference / autograd checks of the formula itself."""
+    if not f32:
+        pr = np.clip(sigmoid(a), BCE_CLIP, BCE_CLIP_HI)
+        return -(t * np.log(pr + BCE_CLIP) + (1.0 - t) * np.log(1.0 - pr + BCE_CLIP))
+    ce, hi, one = np.float32(BCE_CLIP), np.float32(BCE_CLIP_HI), np.float32(1.0)
+    t = np.asarray(t, dtype=np.float32)
+    pr = np.clip(_sigmoid_f32(a), ce, hi)
+    return (-(t * np.log(pr + ce) + (one - t) * np.log(one - pr + ce))).astype(np.float64)
+
+
+def bce_probs_dlogit(a, t, f32=True):
     """d bce_probs / d a: zero where the clip is active (tf.clip_by_value passes no gradient outside its range)."""
-    sg = sigmoid(a)
-    inside = (sg >= BCE_CLIP) & (sg <= 1.0 - BCE_CLIP)
-    pr = np.clip(sg, BCE_CLIP, 1.0 - BCE_CLIP)
-    dpr = -t / (pr + BCE_CLIP) + (1.0 - t) / (1.0 - pr + BCE_CLIP)
-    return dpr * sg * (1.0 - sg) * inside
+    if not f32:
+        sg = sigmoid(a)
+        inside = (sg >= BCE_CLIP) & (sg <= BCE_CLIP_HI)
+        pr = np.clip(sg, BCE_CLIP, BCE_CLIP_HI)
+        dpr = -t / (pr + BCE_CLIP) + (1.0 - t) / (1.0 - pr + BCE_CLIP)
+        return dpr * sg * (1.0 - sg) * inside
+    ce, hi, one = np.float32(BCE_CLIP), np.float32(BCE_CLIP_HI), np.float32(1.0)
+    t = np.asarray(t, dtype=np.float32)
+    sg = _sigmoid_f32(a)
+    inside = (sg >= ce) & (sg <= hi)
+    pr = np.clip(sg, ce, hi)
+    dpr = (one - t) / (one - pr + ce) - t / (pr + ce)
+    return (dpr * sg * (one - sg) * inside).astype(np.float64)
+
+
+# |logit| beyond which float32 rounding of 1 - sigmoid decides the value of the probability form (1 - p < 6e-6):
+# parity tests take the device's own d loss / d logit there (``backward(..., masks={"dlogits": ...})``), as they take
+# its ReLU decisions at the kinks.
+BCE_PROBS_BAND = 12.0
 
 
 def bce_logits(a, t):
@@ -414,7 +450,11 @@ def forward(p, x, eps=None, variant="vae", sem=None):
         z = c["enc.dense.a"]
     decoder_fwd(p, z, c, sem)
     B = x.shape[0]
-    bce = (bce_logits if sem["bce"] == "logits" else bce_probs)(c["logits"], x).mean(axis=-1)   # mean over last axis (size 1)
+    if sem["bce"] == "logits":
+        bce = bce_logits(c["logits"], x)
+    else:
+        bce = bce_probs(c["logits"], x, f32=(sem["bce"] == "probs"))
+    bce = bce.mean(axis=-1)                                       # mean over last axis (size 1)
     c["rec_per_sample"] = bce.sum(axis=(1, 2))
     c["rec_loss"] = c["rec_per_sample"].mean()
     if variant == "vae":
@@ -433,7 +473,8 @@ def backward(p, c, variant="vae", masks=None):
     ``masks`` (optional) maps "<layer>" (e.g. "dec.deconv3", "enc.dense") to a boolean ReLU
     mask that replaces ``a > 0``: a pre-activation within fp32 rounding of 0 has an ambiguous
     sub-gradient, so parity tests evaluate the oracle at the device's ReLU decisions after
-    checking that every disagreement sits at such a kink."""
+    checking that every disagreement sits at such a kink.  ``masks["dlogits"]`` (optional) replaces d total /
+    d logits the same way, for the saturation band of the float32 probability form (``BCE_PROBS_BAND``)."""
     g = {}
     masks = masks or {}
     sem = c.get("sem", resolve_sem(None))       # the switches the forward cache was made with
@@ -445,7 +486,9 @@ def backward(p, c, variant="vae", masks=None):
     if sem["bce"] == "logits":
         dh = (sigmoid(c["logits"]) - x) / B                       # d rec / d logits
     else:
-        dh = bce_probs_dlogit(c["logits"], x) / B
+        dh = bce_probs_dlogit(c["logits"], x, f32=(sem["bce"] == "probs")) / B
+    if "dlogits" in masks:                                        # the caller's d loss / d logits (BCE_PROBS_BAND)
+        dh = np.asarray(masks["dlogits"], dtype=np.float64).reshape(dh.shape)
     g["dlogits"] = dh
     # decoder backwards
     for name, cin, cout, k, s, pad in reversed(DEC_DECONVS):

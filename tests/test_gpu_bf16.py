@@ -94,40 +94,6 @@ def test_bf16_training_reduces_the_loss():
     assert np.isfinite(last) and last < first
 
 
-def test_lean_bf16_gather_kernel_matches_the_general_one():
-    """VEEX_BFV3=1 routes every bf16 gather launch with a bf16 A copy through gather_gemm_bf16_v3.hip.  Same K order
-    inside a dot product, so every activation and input gradient has the same bits; its tiles run over (image row,
-    sample, column), so the per-tile column sums behind bias / gamma / beta gradients are grouped differently and
-    may differ by fp32 rounding of the sum.  Off by default because it measures the same."""
-    import torch
-    from util import LAYERS
-    from vae_eeg_xai_amd import _lib
-    from vae_eeg_xai_amd.net import Net
-    L, B = 28, 200
-    p = vo.init_params(L, "vae", seed=3, jitter=0.1)
-    x = vo.synth_topomaps(B, 5)
-    eps = np.random.default_rng(7).standard_normal((B, L)).astype(np.float32)
-    res = []
-    try:
-        for flag in ("0", "1"):
-            _lib.setenv("VEEX_BFV3", flag)
-            net = Net(L, "vae", compute="bf16")
-            net.set_weights_dict(p)
-            net.train_fwd_bwd(x, eps)
-            torch.cuda.synchronize()
-            res.append((net, net.grads.clone(), {ln: net.ws_region(B, "act." + ln).clone() for ln in LAYERS},
-                        net.ws_region(B, "dpre.enc.conv1").clone()))
-    finally:
-        _lib.setenv("VEEX_BFV3", "0")
-    (n0, g0, a0, d0), (n1, g1, a1, d1) = res
-    for ln in LAYERS:
-        assert torch.equal(a0[ln], a1[ln]), ln
-    assert torch.equal(d0, d1)
-    for name, ref in n0.named_views(g0):
-        got = n1.view([s for s in n1.specs if s.name == name][0], g1)
-        assert ((got - ref).abs().max() / (ref.abs().max() + 1e-30)).item() < 2e-6, name
-
-
 @pytest.mark.parametrize("variant,B", [("vae", 200), ("ae", 167), ("vae", 512)])
 def test_halo_tile_kernel_matches_the_general_bf16_kernel(variant, B):
     """VEEX_HALO=1 (default) routes the 3x3 conv / deconv forwards and input gradients of the bf16 engine through
@@ -239,18 +205,15 @@ def test_halo_tile_launch_equals_the_general_launch(geom, epi):
         torch.cuda.synchronize()
         return out, obf, part, (tuple(plan) if took == 1 else None)
 
-    keys = ("VEEX_HG_G", "VEEX_HG_BANDS", "VEEX_HG_CH", "VEEX_HG_NT", "VEEX_HG_OCC")
     try:
         _lib.setenv("VEEX_HALO", "0")
         ref, rbf, rpart, plan0 = run()
         assert plan0 is None
         _lib.setenv("VEEX_HALO", None)
-        forced = [dict(), dict(VEEX_HG_BANDS=2), dict(VEEX_HG_BANDS=3, VEEX_HG_NT=1), dict(VEEX_HG_G=2, VEEX_HG_CH=64),
-                  dict(VEEX_HG_G=1, VEEX_HG_NT=2, VEEX_HG_OCC=2), dict(VEEX_HG_G=5)]
+        forced = [dict(), dict(bands=2), dict(bands=3, nt=1), dict(G=2, ch=64), dict(G=1, nt=2, occ=2), dict(G=5)]
         ran = 0
         for f in forced:
-            for kk in keys:
-                _lib.setenv(kk, f.get(kk))
+            _lib.setenv("VEEX_HG_PLAN", _lib.hg_plan_code(**f) or None)
             out, obf, part, plan = run()
             if plan is None:
                 continue                      # this forced plan does not fit the layer: the general kernel ran
@@ -266,5 +229,5 @@ def test_halo_tile_launch_equals_the_general_launch(geom, epi):
                 assert (tot - rtot).abs().max().item() <= 2e-5 * rtot.abs().max().item(), (label, f)
         assert ran >= 1 or label in ("conv3.fwd", "deconv1.fwd", "deconv1.dgrad"), label
     finally:
-        for kk in keys + ("VEEX_HALO",):
+        for kk in ("VEEX_HG_PLAN", "VEEX_HALO"):
             _lib.setenv(kk, None)

@@ -17,21 +17,29 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+# (switches, learning rate, tolerance): the alternate Keras readings through the driver.  Batch statistics make the
+# loss chaotic in the step size (tests/test_gpu_net.py), hence the small rate and the wider bound there.
+FIT_SEMS = [(None, 1e-3, 5e-5), ({"bce": "probs"}, 1e-3, 5e-5), ({"bn": "batch"}, 1e-5, 1e-3)]
+
+
+@pytest.mark.parametrize("sem,lr,tol", FIT_SEMS, ids=["default", "bce=probs", "bn=batch"])
 @pytest.mark.parametrize("variant", ["vae", "ae"])
-def test_fit_epoch_metrics_equal_the_oracle_running_means(variant):
+def test_fit_epoch_metrics_equal_the_oracle_running_means(variant, sem, lr, tol):
     if variant == "vae":
         from vae_eeg_xai_amd.models import Encoder, Decoder, VAE as Model, Adam
     else:
         from vae_eeg_xai_amd.models_standard import (EncoderStandard as Encoder, DecoderStandard as Decoder,
                                                      Autoencoder as Model, Adam)
-    N, NV, bs, L, seed, lr, epochs = 20, 12, 8, 8, 3, 1e-3, 2        # batches of 8, 8, 4; validation 8, 4
+    N, NV, bs, L, seed, epochs = 20, 12, 8, 8, 3, 2        # batches of 8, 8, 4; validation 8, 4
     p = vo.init_params(L, variant, seed=4, jitter=0.1)
     x = vo.synth_topomaps(N + NV, 12)
     xt, xv = x[:N], x[N:]
-    model = Model(Encoder(L), Decoder())
+    model = Model(Encoder(L), Decoder(), semantics=sem)
     model._net.set_weights_dict(p)
     model.compile(Adam(lr))
     hist = model.fit(xt, xt, bs, epochs, validation_data=(xv, xv), verbose=0, seed=seed)
+    # validation (test_step) always normalises with the moving statistics, which bn="batch" keeps updating
+    val_sem = dict(sem or {}, bn="inference")
 
     names = vo.trainable_names(L, variant)
     pp = {k: a.copy() for k, a in p.items()}
@@ -48,22 +56,22 @@ def test_fit_epoch_metrics_equal_the_oracle_running_means(variant):
             eps = vo.philox_normal(42, seen, len(idx), L) if variant == "vae" else None
             seen += len(idx)
             t += 1
-            rows.append(vo.train_step(pp, m, v, t, lr, xt[idx], eps, variant))
+            rows.append(vo.train_step(pp, m, v, t, lr, xt[idx], eps, variant, sem))
         train_mean = np.mean(np.asarray(rows, dtype=np.float64), axis=0)         # unweighted over batches (Keras Mean)
         rows = []
         for s in range(0, NV, bs):
             xb = xv[s:s + bs]
             eps = vo.philox_normal(42, seen, len(xb), L) if variant == "vae" else None
             seen += len(xb)
-            c = vo.forward(pp, xb, eps, variant)
+            c = vo.forward(pp, xb, eps, variant, val_sem)
             rows.append((c["total"], c["rec_loss"], c["kl_loss"]))
         val_mean = np.mean(np.asarray(rows, dtype=np.float64), axis=0)
         scale = abs(train_mean[0])
         for i, k in enumerate(keys):
             # 5e-5 of the total loss: the device draws epsilon with fp32 log / sin / cos (2e-5 absolute of the float64
             # restatement, tests/test_gpu_net.py), and Adam at lr 1e-3 carries that into the later batches
-            assert abs(hist.history[k][epoch] - train_mean[i]) < 5e-5 * scale, (epoch, k, hist.history[k][epoch], train_mean[i])
-            assert abs(hist.history["val_" + k][epoch] - val_mean[i]) < 5e-5 * scale, (epoch, k)
+            assert abs(hist.history[k][epoch] - train_mean[i]) < tol * scale, (epoch, k, hist.history[k][epoch], train_mean[i])
+            assert abs(hist.history["val_" + k][epoch] - val_mean[i]) < tol * max(scale, abs(val_mean[0])), (epoch, k)
     assert model._net.samples_seen == seen
 
 

@@ -63,11 +63,11 @@ def test_lean_gather_kernel_is_bit_identical_to_the_general_one(case):
         d.out = tmp.data_ptr()
         mt = lib.veex_gather_gemm_m_tiles(C.byref(d))
         assert mt > 0
-    saved = {v: os.environ.get(v) for v in ("VEEX_GGV3", "VEEX_ROWORD", "VEEX_TILEPERM")}
+    saved = {v: os.environ.get(v) for v in ("VEEX_GGV3",)}
     res = []
     try:
-        for v3, ro, perm in (("0", "0", "0"), ("1", "0", "0"), ("1", "1", "0"), ("1", "2", "0"), ("1", "2", "1")):
-            _lib.setenv("VEEX_GGV3", v3); _lib.setenv("VEEX_ROWORD", ro); _lib.setenv("VEEX_TILEPERM", perm)
+        for v3 in ("0", "1"):
+            _lib.setenv("VEEX_GGV3", v3)
             out = torch.full((N, Hout, Hout, Cout), 7.0, device="cuda")
             d.out = out.data_ptr()
             part = None
@@ -82,14 +82,10 @@ def test_lean_gather_kernel_is_bit_identical_to_the_general_one(case):
             _lib.setenv(v, val)
     ref = res[0][0]
     assert torch.isfinite(ref).all() and float(ref.abs().max()) > 0
-    assert torch.equal(ref, res[1][0]), "lean kernel, sample-major tiles"
-    assert torch.equal(ref, res[2][0]), "lean kernel, row-major tiles with skipped padding taps"
-    assert torch.equal(ref, res[3][0]), "lean kernel, one output pixel per tile"
-    assert torch.equal(ref, res[4][0]), "lean kernel, one output pixel per tile, centre-out"
+    assert torch.equal(ref, res[1][0]), "lean kernel (its tile order: one output pixel per tile, centre-out, where it applies)"
     if epi == 1:
-        assert torch.equal(res[0][1], res[1][1])
         ta = res[0][1].view(mt, 3, Cout).sum(0)
-        for r in res[2:]:
+        for r in res[1:]:
             tc = r[1].view(mt, 3, Cout).sum(0)
             assert float((ta - tc).abs().max()) <= 1e-5 * float(ta.abs().max())
 

@@ -131,7 +131,9 @@ def test_golden_fixtures_reproduce(path, variant, L, B, seed):
     assert rel_err(sal, f["saliency"]) < 1e-12
 
 
-SEMS = [{"bn": "batch"}, {"bce": "probs"}, {"bn": "batch", "bce": "probs"}]
+# "probs64": the probability form in real arithmetic (the formula and its derivative are what these tests check);
+# sem "probs" evaluates it in float32, as Keras does -- test_probability_bce_float32_evaluation below
+SEMS = [{"bn": "batch"}, {"bce": "probs64"}, {"bn": "batch", "bce": "probs64"}]
 
 
 @pytest.mark.parametrize("sem", SEMS, ids=lambda s: "+".join(f"{k}={v}" for k, v in s.items()))
@@ -178,13 +180,35 @@ def test_alternate_keras_semantics_finite_differences(sem):
 def test_probability_bce_is_the_logit_form_away_from_saturation_and_clips_at_it():
     a = np.array([-30.0, -17.0, -3.0, 0.0, 2.5, 17.0, 30.0])
     t = np.array([0.0, 0.3, 1.0, 0.5, 0.2, 1.0, 0.4])
-    lo, pr = vo.bce_logits(a, t), vo.bce_probs(a, t)
+    lo, pr = vo.bce_logits(a, t), vo.bce_probs(a, t, f32=False)
     # the +1e-7 inside the logarithms shifts a term by ~1e-7 / p: 2e-6 at p = 0.05 -- the two forms differ at the
     # 1e-6 .. 1e-5 level in loss and gradients (SURVEY A.4 says "<~ 1e-7"), i.e. right at the parity tolerance
     assert np.allclose(lo[2:5], pr[2:5], rtol=0, atol=5e-6)
-    assert abs(pr[0] - (-np.log(1 - 1e-7 + 1e-7))) < 1e-12 and abs(pr[6] - (-(0.4 * np.log(1.0) + 0.6 * np.log(2e-7)))) < 1e-7
-    d = vo.bce_probs_dlogit(a, t)
+    assert abs(pr[0] - (-np.log(1 - vo.BCE_CLIP + vo.BCE_CLIP))) < 1e-12
+    # float32's 1 - 1e-7 is 1 - 2**-23: a saturated pixel costs -log(2.19e-7)
+    assert abs(pr[6] - (-(0.4 * np.log(1.0) + 0.6 * np.log(2.0 ** -23 + 1e-7)))) < 1e-6
+    d = vo.bce_probs_dlogit(a, t, f32=False)
     assert d[0] == 0.0 and d[6] == 0.0 and d[4] != 0.0                # no gradient through an active clip
+
+
+def test_probability_bce_float32_evaluation():
+    """sem "probs" follows Keras's float32 arithmetic: equal to the real-arithmetic formula below the saturation band
+    (to float32 rounding), a different -- piecewise constant -- function inside it."""
+    rng = np.random.default_rng(0)
+    a = rng.uniform(-vo.BCE_PROBS_BAND, vo.BCE_PROBS_BAND, 4000)
+    t = rng.uniform(0, 1, 4000)
+    assert np.abs(vo.bce_probs(a, t) - vo.bce_probs(a, t, f32=False)).max() < 2e-2      # 6e-8 / (1 - p) at |a| = 12
+    m = np.abs(a) < 6
+    assert np.abs(vo.bce_probs(a, t) - vo.bce_probs(a, t, f32=False))[m].max() < 5e-5
+    dd = np.abs(vo.bce_probs_dlogit(a, t) - vo.bce_probs_dlogit(a, t, f32=False))
+    assert dd.max() < 3e-4 and dd[np.abs(a) < 8].max() < 1e-6
+    # inside the band: float32's sigmoid is exactly 1 from a = 16.7 on and the clip edge moves to where 1 - p rounds
+    hi = np.array([15.0, 15.5, 15.9, 16.3, 17.0, 40.0])
+    d32, d64 = vo.bce_probs_dlogit(hi, np.zeros(6)), vo.bce_probs_dlogit(hi, np.zeros(6), f32=False)
+    assert d32[-1] == 0.0 and d64[-1] == 0.0 and d32[0] > 0.5
+    assert np.abs(d32 - d64).max() > 0.1                              # the discontinuity the band exists for
+    c32 = vo.bce_probs(hi, np.zeros(6))
+    assert abs(c32[-1] - (-np.log(2.0 ** -23 + 1e-7))) < 1e-6
 
 
 def test_batch_statistics_mode_updates_the_moving_statistics():

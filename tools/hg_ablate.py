@@ -8,8 +8,7 @@ from vae_eeg_xai_amd import _lib, roofline as rl  # noqa: E402
 from hg_sweep import timed  # noqa: E402
 
 B, want = int(sys.argv[1]), sys.argv[2]
-for k, v in zip(("VEEX_HG_G", "VEEX_HG_BANDS", "VEEX_HG_CH", "VEEX_HG_NT"), sys.argv[3:7]):
-    _lib.setenv(k, v)
+_lib.setenv("VEEX_HG_PLAN", _lib.hg_plan_code(*[int(v) for v in sys.argv[3:7]]))
 for label, macs, fn in rl.gemm_cases(B, True):
     if label != want:
         continue

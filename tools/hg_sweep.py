@@ -1,6 +1,6 @@
 """Sweep the plan of the halo-tile bf16 kernel (halo_gemm_bf16.hip) per launch of one train step: samples per
 workgroup / bands per sample, resident channel slice, channel tile, register bound -- each forced through the
-VEEX_HG_* switches, timed with HIP events beside the general bf16 kernel (VEEX_HALO=0) in ONE process.
+VEEX_HG_PLAN switch, timed with HIP events beside the general bf16 kernel (VEEX_HALO=0) in ONE process.
 usage: python tools/hg_sweep.py [batch] [label-substring ...]"""
 import ctypes as C
 import itertools
@@ -35,13 +35,11 @@ def timed(fn, iters=12):
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     want = sys.argv[2:]
-    keys = ("VEEX_HG_G", "VEEX_HG_BANDS", "VEEX_HG_CH", "VEEX_HG_NT", "VEEX_HG_OCC")
     for label, macs, fn in rl.gemm_cases(B, True):
         if label.endswith("wgrad") or (want and not any(w in label for w in want)):
             continue
         d = fn.__defaults__[0]
-        for k in keys:
-            _lib.setenv(k, None)
+        _lib.setenv("VEEX_HG_PLAN", None)
         _lib.setenv("VEEX_HALO", "0")
         t_gen = timed(fn)
         _lib.setenv("VEEX_HALO", None)
@@ -53,8 +51,7 @@ def main():
         for G, nb, CH, NT in itertools.product((1, 2, 3, 4, 6, 8, 12, 16), (1, 2, 3, 4, 6), (64, 128, 256), (1, 2)):
             if G > 1 and nb > 1:
                 continue
-            for k, v in zip(keys, (G, nb, CH, NT, None)):
-                _lib.setenv(k, v)
+            _lib.setenv("VEEX_HG_PLAN", _lib.hg_plan_code(G, nb, CH, NT))
             if lib.veexi_debug_hg_plan(C.byref(d), out) != 1:
                 continue
             plan = tuple(out)[:7]
@@ -62,10 +59,9 @@ def main():
                 continue
             seen.add(plan)
             for occ in ((4, 2) if plan[3] * plan[4] <= 3 else (2,)):
-                _lib.setenv("VEEX_HG_OCC", occ)
+                _lib.setenv("VEEX_HG_PLAN", _lib.hg_plan_code(G, nb, CH, NT, occ))
                 res.append((timed(fn), f"G={G} bands={nb} CH={CH} NT={NT} occ={occ}", tuple(out)))
-        for k in keys:
-            _lib.setenv(k, None)
+        _lib.setenv("VEEX_HG_PLAN", None)
         res.sort(key=lambda r: r[0])
         print(f"{label:20s} general {t_gen:7.1f} us | " + (" | ".join(f"{t:6.1f} us {c} (mt {p[3]} lds {p[5] // 1024}K wgs {p[6]})" for t, c, p in res[:4]) if res else "halo kernel does not take it"), flush=True)
         for t, c, p in res:

@@ -154,6 +154,13 @@ def setenv(name: str, value) -> None:
     lib.veexi_debug_reload_env()
 
 
+def hg_plan_code(G: int = 0, bands: int = 0, ch: int = 0, nt: int = 0, occ: int = 0) -> int:
+    """Value of VEEX_HG_PLAN that forces the halo-tile kernel's plan (csrc/halo_gemm_bf16.hip hg_forced): samples per
+    workgroup, bands of output rows, channel slice (multiple of 32), 64-column sub-tiles, waves per SIMD; 0 = search."""
+    assert 0 <= bands < 10 and ch % 32 == 0 and 0 <= ch // 32 < 100 and 0 <= nt < 10 and 0 <= occ < 10
+    return G * 100000 + bands * 10000 + (ch // 32) * 100 + nt * 10 + occ
+
+
 def check(rc: int, what: str = "veex call"):
     if rc != 0:
         raise VeexError(f"{what} failed (rc={rc}): {lib.veex_last_error().decode()}")

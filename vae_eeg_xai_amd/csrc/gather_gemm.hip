@@ -554,7 +554,7 @@ int veex_gg_bm(const GGParams& p) {
   const long long M = (long long)p.Nb * p.Hout * p.Wout;
   if (veex_gg_v4_ok(p)) return 32;   // small launches: 32x32 tiles, K split over the waves of a block (gather_gemm_v4.hip)
   if (M < 4096) return 64;
-  const int force = veex_env_int("VEEX_BM", 0);
+  const int force = veex_tune_int("VEEX_BM", 0);
   if (force == 64 || force == 128) return force;
   if (p.Wbf == nullptr && veex_env_int("VEEX_GGV3", 1) && gg_fast_ok_fwd(p) && veex_gg_v3_ok(p)) return veex_gg_v3_bm(p);   // lean fp32 kernel
   if (p.Wbf == nullptr || p.Cin % 32 != 0) return 64;
@@ -632,16 +632,12 @@ static int gg_launch_fast(const GGParams& p, dim3 grid, hipStream_t st) {
         gg_set_lds(gather_gemm_kernel<BM, BN, 2, 2, MODE1, 2, BK>, lds)) return -3;
     attr_done = true;
   }
-  if constexpr (BM == 64 && BN == 64 && BK == 16) {
-    // V2 (see the kernel); VEEX_GGV2=0 keeps the first version for A/B timing
-    const int v2 = veex_env_int("VEEX_GGV2", 1);
-    if (v2 >= 1) {
-      if (aff == 0) hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 2, 2, MODE1, 0, BK, 0, 1>), grid, dim3(256), lds, st, p);
-      else if (aff == 1) hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 2, 2, MODE1, 1, BK, 0, 1>), grid, dim3(256), lds, st, p);
-      else hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 2, 2, MODE1, 2, BK, 0, 1>), grid, dim3(256), lds, st, p);
-      VEEX_CHECK_LAUNCH();
-      return 0;
-    }
+  if constexpr (BM == 64 && BN == 64 && BK == 16) {   // V2 of the K loop (see the kernel)
+    if (aff == 0) hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 2, 2, MODE1, 0, BK, 0, 1>), grid, dim3(256), lds, st, p);
+    else if (aff == 1) hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 2, 2, MODE1, 1, BK, 0, 1>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 2, 2, MODE1, 2, BK, 0, 1>), grid, dim3(256), lds, st, p);
+    VEEX_CHECK_LAUNCH();
+    return 0;
   }
   if (aff == 0) hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 2, 2, MODE1, 0, BK>), grid, dim3(256), lds, st, p);
   else if (aff == 1) hipLaunchKernelGGL((gather_gemm_kernel<BM, BN, 2, 2, MODE1, 1, BK>), grid, dim3(256), lds, st, p);
@@ -655,13 +651,13 @@ static int gg_launch_cfg(GGParams& p, int mtiles, bool fast, hipStream_t st) {
   const int ntiles = (p.Cout + BN - 1) / BN;
   // XCD-contiguous block order: neutral on single-phase layers, but on the 4-phase (stride-2 deconv)
   // launches whole XCDs would get only 4-tap or only 1-tap tiles (+30..50 % time): round-robin there
-  const int xr = veex_env_int("VEEX_XCD", -1);
+  const int xr = veex_tune_int("VEEX_XCD", -1);
   p.remap = (xr < 0) ? (p.nphase == 1) : xr;
-  p.tap_inner = veex_env_int("VEEX_TAPIN", 1);   // measured -1..-4 % on every layer
+  p.tap_inner = 1;   // taps innermost: measured -1..-4 % on every layer
   p.gx = ntiles; p.gy = mtiles; p.gz = p.nsplit;
   dim3 grid((unsigned)ntiles * mtiles * p.nsplit, 1, 1);
   if (fast) {
-    const int want32 = veex_env_int("VEEX_BK", 16) == 32;
+    const int want32 = veex_tune_int("VEEX_BK", 16) == 32;
     const bool bk32 = want32 && ((p.kh * p.kw == 1) || (p.Cin % 32 == 0));
     const int bk = bk32 ? 32 : 16;
     if (p.nsplit > 1) {
@@ -788,7 +784,7 @@ extern "C" int veexi_debug_gather_gemm(const GGParams* pin, int dbg, hipStream_t
   const int mtiles = veex_gg_m_tiles_bm(p, 64);
   p.nsplit = 1; p.chunks_per_split = 1 << 30;
   p.gx = (p.Cout + 63) / 64; p.gy = mtiles; p.gz = 1;
-  p.remap = (p.nphase == 1); p.tap_inner = veex_env_int("VEEX_TAPIN", 1);
+  p.remap = (p.nphase == 1); p.tap_inner = 1;
   dim3 grid(mtiles * p.gx, 1, 1);
   constexpr size_t lds = gg_lds_bytes<64, 64, true, 16>();
   if (p.mode == 1) {

@@ -404,7 +404,7 @@ static int ggb_launch(const GGParams& p, dim3 grid, hipStream_t st) {
     // K chunks of 64 channels (half the barriers and loop overhead, twice the LDS, so fewer resident blocks):
     // measured per layer at B=512 it wins where the K loop per tap is long (Cin >= 128) and the launch is at most
     // ~4 blocks per CU, and loses on the large grids.  VEEX_BFBK=32/64 forces one of them.
-    const int bfbk = veex_env_int("VEEX_BFBK", 0);
+    const int bfbk = veex_tune_int("VEEX_BFBK", 0);
     const bool auto64 = p.Cin >= 128 && (long long)grid.x <= 1024;
     if (p.Cin % 64 == 0 && (bfbk == 64 || (bfbk == 0 && auto64))) {
       constexpr size_t lds64 = ggb_lds_bytes<BM, BN, 64>();
@@ -434,17 +434,13 @@ int veex_launch_gather_gemm_bf16(GGParams& p, int mtiles, hipStream_t st) {
   if ((long long)p.Nb * p.Hout * p.Wout >= (1LL << 24)) { veex_set_error("gather_gemm(bf16): more than 2^24 output pixels"); return -1; }
   if ((long long)p.Nb * p.Hout * p.Wout * p.Cout * 4 >= 0x7FFF0000LL) { veex_set_error("gather_gemm(bf16): output of 2 GiB or more"); return -1; }
   const int bm = veex_gg_bm(p);
-  // The lean kernel (gather_gemm_bf16_v3.hip) can take every launch whose A operand is a bf16 consumer copy.  Off by
-  // default: it issues 3-8x fewer instructions per MFMA and keeps up to 4 chunks of loads in flight, and measures
-  // the same (+-3 %) -- these launches are bound by what a CU can gather from L2, not by issue.
-  if (veex_env_int("VEEX_BFV3", 0) && veex_gg_bf16_v3_ok(p)) return veex_launch_gather_gemm_bf16_v3(p, mtiles, bm, st);
   const int bn = (bm == 128 && p.Cout > 64) ? 128 : 64;
   const int ntiles = (p.Cout + bn - 1) / bn;
   if (p.nsplit > 1) {
     const int nchunks = p.kh * p.kw * (p.Cin / 32);
     p.chunks_per_split = (nchunks + p.nsplit - 1) / p.nsplit;
   }
-  const int xr = veex_env_int("VEEX_XCD", -1);
+  const int xr = veex_tune_int("VEEX_XCD", -1);
   p.remap = (xr < 0) ? (p.nphase == 1) : xr;
   p.gx = ntiles; p.gy = mtiles; p.gz = p.nsplit;
   dim3 grid((unsigned)ntiles * mtiles * p.nsplit, 1, 1);

@@ -502,36 +502,26 @@ int veex_gg_v3_ok(const GGParams& p) {
   return 1;
 }
 
-// Tile of the lean kernel for this launch: rows (64 or 128; veex_gg_bm is the one source: callers size the column
-// partials by it) x columns.  Wide tiles need the [n][k] weight layout: mode 1, or mode 0 with the packed copy.
-int veex_gg_v3_bm(const GGParams& p) {
-  const long long M = (long long)p.Nb * p.Hout * p.Wout;
-  if (veex_env_int("VEEX_F32BM", 64) != 128 || M < 8192 || p.nsplit > 1) return 64;
-  if (!(p.mode == 1 || (p.Wt != nullptr && veex_env_int("VEEX_WPACKF", 1)))) return 64;
-  return 128;
-}
-static int gg_v3_bn(const GGParams& p) {
-  if (veex_env_int("VEEX_F32BN", 64) != 128 || p.Cout < 128 || p.nsplit > 1) return 64;
-  if (!(p.mode == 1 || (p.Wt != nullptr && veex_env_int("VEEX_WPACKF", 1)))) return 64;
-  return 128;
-}
+// Tile of the lean kernel: 64 x 64 (veex_gg_bm is the one source of the row count: callers size the column partials
+// by it).  128-row / 128-column tiles were measured slower on every layer (profiles/r02_f32_tiles.txt) and are gone.
+int veex_gg_v3_bm(const GGParams&) { return 64; }
 
 // p: validated by veex_launch_gather_gemm, phase tables filled for veex_gg_bm(p)-row tiles
 int veex_launch_gather_gemm_v3(GGParams& p, int mtiles, hipStream_t st) {
-  const int bm = veex_gg_v3_bm(p), bn = gg_v3_bn(p);
+  constexpr int bm = 64, bn = 64;
   const int ntiles = (p.Cout + bn - 1) / bn;
   if (p.nsplit > 1) {
     const int nchunks = p.kh * p.kw * (p.Cin / 16);
     p.chunks_per_split = (nchunks + p.nsplit - 1) / p.nsplit;
   }
-  const int xr = veex_env_int("VEEX_XCD", -1);
+  const int xr = veex_tune_int("VEEX_XCD", -1);
   p.remap = (xr < 0) ? (p.nphase == 1) : xr;
   p.gx = ntiles; p.gy = mtiles; p.gz = p.nsplit;
   dim3 grid((unsigned)ntiles * mtiles * p.nsplit, 1, 1);
   // one image row per tile wherever a launch has vertically padded taps to skip (A/B at batch 512: -2...-8 % on
   // those launches, +3 % on a launch without padding, whose tiles then only lose locality)
   const bool vpad = (p.mode == 1) ? true : (p.pb > 0 || (p.Hout - 1) * p.stride + p.kh - 1 - p.pb >= p.Hin);
-  const int ro = veex_env_int("VEEX_ROWORD", 2);
+  const int ro = veex_tune_int("VEEX_ROWORD", 2);
   p.row_order = (p.kh > 1 && p.nsplit == 1 && vpad) ? (ro > 1 ? 1 : ro) : 0;
   // one output PIXEL per tile (its rows = bm consecutive samples) when the batch is a multiple of the tile height:
   // every row of the tile then has the same valid taps, vertically AND horizontally, and the tile executes exactly
@@ -540,7 +530,7 @@ int veex_launch_gather_gemm_v3(GGParams& p, int mtiles, hipStream_t st) {
     // interior-first pixel order for one-phase launches (the 4-phase launches already run their longest phase first).
     // Border widths = output rows / columns with fewer than kh valid taps, low and high side (square maps).
     p.row_order = 2;
-    if (p.nphase == 1 && veex_env_int("VEEX_TILEPERM", 1)) {
+    if (p.nphase == 1 && veex_tune_int("VEEX_TILEPERM", 1)) {
       int lo, hi;
       if (p.mode == 1) { lo = p.kh - 1 - p.pb; hi = p.Hout - p.Hin + p.pb; }                       // stride 1 here
       else { lo = (p.pb + p.stride - 1) / p.stride; hi = p.Hout - 1 - (p.Hin - p.kh + p.pb) / p.stride; }
@@ -565,20 +555,12 @@ int veex_launch_gather_gemm_v3(GGParams& p, int mtiles, hipStream_t st) {
   }
   const int aff = (p.a_scale == nullptr) ? 0 : (p.aff_spatial ? 2 : 1);
 #ifdef VEEX_DEBUG_TIMING
-  p.tap_inner = veex_env_int("VEEX_F32DBG", 0);
+  p.tap_inner = veex_tune_int("VEEX_F32DBG", 0);
 #endif
-  const bool bpk = p.mode == 0 && p.Wt != nullptr && veex_env_int("VEEX_WPACKF", 1);
-  if (bm == 64 && bn == 64) {
-    if (p.mode == 1) gg3_launch<true, false, 2, 2>(p, aff, grid, st);
-    else if (bpk) gg3_launch<false, true, 2, 2>(p, aff, grid, st);
-    else gg3_launch<false, false, 2, 2>(p, aff, grid, st);
-  } else if (bm == 128 && bn == 64) {
-    if (p.mode == 1) gg3_launch<true, false, 4, 2>(p, aff, grid, st); else gg3_launch<false, true, 4, 2>(p, aff, grid, st);
-  } else if (bm == 64 && bn == 128) {
-    if (p.mode == 1) gg3_launch<true, false, 2, 4>(p, aff, grid, st); else gg3_launch<false, true, 2, 4>(p, aff, grid, st);
-  } else {
-    if (p.mode == 1) gg3_launch<true, false, 4, 4>(p, aff, grid, st); else gg3_launch<false, true, 4, 4>(p, aff, grid, st);
-  }
+  const bool bpk = p.mode == 0 && p.Wt != nullptr && veex_tune_int("VEEX_WPACKF", 1);
+  if (p.mode == 1) gg3_launch<true, false, 2, 2>(p, aff, grid, st);
+  else if (bpk) gg3_launch<false, true, 2, 2>(p, aff, grid, st);
+  else gg3_launch<false, false, 2, 2>(p, aff, grid, st);
   VEEX_CHECK_LAUNCH();
   return 0;
 }

@@ -263,7 +263,7 @@ int veex_gg_v4_ok(const GGParams& p) {
   //   batch 128: off 0.988 ms,         < 128: 0.992, < 256: 1.003, < 512: 1.025;   batch >= 256: no launch below 256
   const long long M = (long long)p.Nb * p.Hout * p.Wout;
   const long long blocks64 = ((M + 63) / 64) * ((p.Cout + 63) / 64);
-  return blocks64 < veex_env_int("VEEX_V4_BLOCKS", 256);
+  return blocks64 < veex_tune_int("VEEX_V4_BLOCKS", 256);
 }
 
 // p: validated by veex_launch_gather_gemm, phase tables filled for 32-row tiles

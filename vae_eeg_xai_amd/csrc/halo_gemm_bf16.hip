@@ -493,7 +493,7 @@ static int hg_bands(const GGParams& p, HGPlan& h) {
 // Picks samples per workgroup / bands per sample, the resident channel slice and the channel tile by a small cost
 // model: MFMA cycles of the fullest SIMD against the weight bytes the workgroup pulls through L2 (~24 B/clk per CU in
 // practice), plus staging and epilogue, which only overlap with another workgroup's K loop when two or more fit on a
-// CU.  VEEX_HG_G / _BANDS / _CH / _NT force a choice (A/B sweeps).  Returns false when the launch does not fit.
+// CU.  VEEX_HG_PLAN forces a choice (tests, A/B sweeps).  Returns false when the launch does not fit.
 static bool hg_plan_search(const GGParams& pin, HGPlan& best);
 // The search walks a few hundred candidate plans: far too slow for the launch path (a whole-step call asks for the
 // plan of each launch three times), so plans are cached per geometry; a re-read of the switches drops the cache.
@@ -537,11 +537,19 @@ static const HGKnown HG_KNOWN[] = {
     {1, 2, 19, 64, 64, 1, 2, 64, 1},     // dec.deconv5 forward
     {0, 2, 39, 64, 64, 0, 0, 0, 0},      // dec.deconv5 input gradient
 };
+// VEEX_HG_PLAN forces a plan instead of the table's (tests, tools/hg_sweep.py): decimal digits G*100000 + bands*10000 +
+// (CH/32)*100 + NT*10 + OCC, each field 0 = leave it to the search (vae_eeg_xai_amd/_lib.py hg_plan_code)
+struct HGForce { int G, bands, CH, NT, occ; };
+static HGForce hg_forced() {
+  const int v = veex_env_int("VEEX_HG_PLAN", 0);
+  return HGForce{v / 100000, (v / 10000) % 10, ((v / 100) % 100) * 32, (v / 10) % 10, v % 10};
+}
 static bool hg_plan_search(const GGParams& pin, HGPlan& best) {
   GGParams p = pin;
   int kG = 0, kB = 0, kC = 0, kN = 0;
+  const HGForce f = hg_forced();
   {
-    const bool forced = veex_env_int("VEEX_HG_G", 0) || veex_env_int("VEEX_HG_BANDS", 0) || veex_env_int("VEEX_HG_CH", 0) || veex_env_int("VEEX_HG_NT", 0);
+    const bool forced = f.G || f.bands || f.CH || f.NT;
     const HGKnown* k = nullptr;
     for (const HGKnown& e : HG_KNOWN)
       if (e.mode == p.mode && e.stride == p.stride && e.Hin == p.Hin && e.Cin == p.Cin && e.Cout == p.Cout && p.kh == 3) k = &e;
@@ -554,8 +562,8 @@ static bool hg_plan_search(const GGParams& pin, HGPlan& best) {
   if (p.Cin != 64 && p.Cin != 128 && p.Cin != 256) return false;
   if (p.Cout % 64 != 0 || p.kh * p.kw > 9 || p.kh != p.kw) return false;
   veex_gg_m_tiles_bm(p, 64);   // fills nphase, Hp, Wp, o0
-  const int fG = kG ? kG : veex_env_int("VEEX_HG_G", 0), fB = kB ? kB : veex_env_int("VEEX_HG_BANDS", 0);
-  const int fC = kC ? kC : veex_env_int("VEEX_HG_CH", 0), fN = kN ? kN : veex_env_int("VEEX_HG_NT", 0);
+  const int fG = kG ? kG : f.G, fB = kB ? kB : f.bands;
+  const int fC = kC ? kC : f.CH, fN = kN ? kN : f.NT;
   bool found = false;
   for (int nt = 1; nt <= 2; ++nt) {
     const int bn = 32 * nt * HG_WN;
@@ -612,7 +620,7 @@ static bool hg_plan_search(const GGParams& pin, HGPlan& best) {
           found = true;
           best = h;
           best.res = res;
-          best.stagger = veex_env_int("VEEX_HG_STAGGER", 0);   // measured: every unit of delay is paid in full (profiles/r03_halo_stagger.txt); off
+          best.stagger = veex_tune_int("VEEX_HG_STAGGER", 0);   // measured: every unit of delay is paid in full (profiles/r03_halo_stagger.txt); off
           best.groups = groups; best.ntn = ntn; best.CH = CH; best.rowbytes = rowbytes; best.zoff = (int)halo;
           best.lds_b = (int)lds_b; best.lds_tab = (int)lds_tab; best.cshift = cshift; best.mt = mt; best.nt = nt;
           best.lds_bytes = lds; best.cost = cost;
@@ -670,13 +678,13 @@ int veex_launch_halo_gemm_bf16(GGParams& p, hipStream_t st) {
   if (!hg_plan(p, h)) { veex_set_error("halo_gemm(bf16): launch does not fit"); return -1; }
   veex_gg_m_tiles_bm(p, 64);   // phase tables (nphase, Hp, Wp, o0)
 #ifdef VEEX_DEBUG_TIMING
-  h.dbg = veex_env_int("VEEX_HG_DBG", 0);
+  h.dbg = veex_tune_int("VEEX_HG_DBG", 0);
 #endif
-  if (veex_env_int("VEEX_HG_VERBOSE", 0))
+  if (veex_tune_int("VEEX_HG_VERBOSE", 0))
     fprintf(stderr, "[halo] mode %d s%d %dx%dx%d -> %dx%dx%d epi %d: G %d bands %d CH %d mt %d nt %d lds %zu wgs %d cost %.0f\n", p.mode, p.stride,
             p.Hin, p.Win, p.Cin, p.Hout, p.Wout, p.Cout, p.epi, h.G, h.nbands, h.CH, h.mt, h.nt, h.lds_bytes, h.groups * h.nbands * h.ntn, h.cost);
   const bool m1 = p.mode == 1;
-  const int occ = veex_env_int("VEEX_HG_OCC", 4);
+  const int occ = hg_forced().occ ? hg_forced().occ : 4;
 #define HG_CASE(MT_, NT_) if (h.mt == MT_ && h.nt == NT_) return m1 ? hg_launch<true, MT_, NT_, 2>(p, h, st) : hg_launch<false, MT_, NT_, 2>(p, h, st);
 #define HG_CASE2(MT_, NT_) if (h.mt == MT_ && h.nt == NT_ && occ == 4) return m1 ? hg_launch<true, MT_, NT_, 4>(p, h, st) : hg_launch<false, MT_, NT_, 4>(p, h, st);
   HG_CASE2(1, 1) HG_CASE2(2, 1) HG_CASE2(3, 1) HG_CASE2(1, 2)

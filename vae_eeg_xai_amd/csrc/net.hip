@@ -441,8 +441,8 @@ static SplitPlan wgrad_split(const WGParams& pin) {
   // (the bf16 copy kernel holds 72 KB of LDS: 2 blocks per CU)
   // (bf16 copy kernel, 72 KB of LDS: ONE block per CU measured best inside the step -- 1.209 -> 1.176 ms at batch 512
   //  against two per CU, -0.8 % at batch 2 048: half the slab bytes, and the input-gradient launches keep the other slot)
-  const int target = veex_env_int("VEEX_WG_BLOCKS", (pin.bf16 == 2) ? 256 : 768);
-  int ns = veex_env_int("VEEX_WG_FLOOR", 1) ? target / tiles : (target + tiles - 1) / tiles;
+  const int target = veex_tune_int("VEEX_WG_BLOCKS", (pin.bf16 == 2) ? 256 : 768);
+  int ns = veex_tune_int("VEEX_WG_FLOOR", 1) ? target / tiles : (target + tiles - 1) / tiles;
   const int maxs = (chunks / 4 > 0) ? chunks / 4 : 1;
   if (ns > maxs) ns = maxs;
   if (ns < 1) ns = 1;
@@ -729,7 +729,7 @@ static const void* packed_w(const Ctx& c, int i, int fwd) {
 static void* bfp(const Ctx& c, long long off) { return (off < 0) ? nullptr : static_cast<void*>(c.ws + off); }
 // pointer to a BatchNorm-applied fp32 copy (nullptr in bf16 mode, or with VEEX_BNCOPY=0: consumers then apply the affine)
 // (nor with batch statistics: a producer cannot apply a normalisation whose statistics are its own output's)
-static float* bnp(const Ctx& c, long long off) { return (off < 0 || c.batch_bn || !veex_env_int("VEEX_BNCOPY", 1)) ? nullptr : c.ws + off; }
+static float* bnp(const Ctx& c, long long off) { return (off < 0 || c.batch_bn || !veex_tune_int("VEEX_BNCOPY", 1)) ? nullptr : c.ws + off; }
 
 // VEEX_BN_BATCH: statistics of layer l's activation -> its scale / shift / rstd / mean slots, moving statistics updated
 static int bn_batch_forward(Ctx& c, const ConvLayer& l, const float* act) {
@@ -918,7 +918,7 @@ static void deconv_dgrad_desc(Ctx& c, int i, GGParams& p) {
 // bf16 engine: true when both of them read only the bf16 copy, so that the producer need not write the fp32 one
 // (372 MB less to write per step at batch 512)
 static bool dpre_dc_f32_unused(Ctx& c, int i) {
-  if (c.n->compute != VEEX_COMPUTE_BF16 || !veex_env_int("VEEX_BF_SKIPF32", 1)) return false;
+  if (c.n->compute != VEEX_COMPUTE_BF16 || !veex_tune_int("VEEX_BF_SKIPF32", 1)) return false;
   WGParams w; deconv_wgrad_desc(c, i, w);
   const SplitPlan s = wgrad_split(w);
   w.nsplit = s.nsplit; w.rows_per_split = s.per;
@@ -941,7 +941,7 @@ static int defer_colsum(Ctx& c, const float* partials, int T, long long row_stri
   memset(&e, 0, sizeof(e));
   e.partials = partials; e.T = T; e.row_stride = row_stride; e.ncols = ncols; e.nch = nch;
   e.e_scale = e_scale; e.mean = mean; e.rstd = rstd; e.dbias = dbias; e.dgamma = dgamma; e.dbeta = dbeta;
-  if (!veex_env_int("VEEX_COLSUM_DEFER", 1)) {   // A/B switch: finalise right away (two launches per entry)
+  if (!veex_tune_int("VEEX_COLSUM_DEFER", 1)) {   // A/B switch: finalise right away (two launches per entry)
     const int rc = veex_colsum_batch(c.fin, c.ws + c.plan.partials2, c.plan.partials2_n, c.st);
     c.fin.n = 0;
     return rc;

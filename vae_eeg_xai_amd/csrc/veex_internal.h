@@ -106,6 +106,13 @@ __device__ __forceinline__ void veex_block_coords(int remap, int gx, int gy, int
 
 int veex_env_generation(void);                  // changes whenever veexi_debug_reload_env() made the switches stale
 int veex_env_int(const char* name, int dflt);   // read once per process and frozen; veexi_debug_reload_env() re-reads
+// Tuning knobs of the A/B sweeps behind DESIGN 5.1's table: they exist only in the tuning build (make TIMING=1).  In
+// the shipped library every one of them is its default, a constant the compiler folds (its other branch is not built).
+#ifdef VEEX_DEBUG_TIMING
+inline int veex_tune_int(const char* name, int dflt) { return veex_env_int(name, dflt); }
+#else
+inline int veex_tune_int(const char*, int dflt) { return dflt; }
+#endif
 
 // launchers (host side; enqueue only, no sync, no allocation)
 int veex_launch_gather_gemm(const GGParams& p, hipStream_t st);

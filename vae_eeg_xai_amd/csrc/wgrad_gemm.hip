@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGParams p) {
 int veex_wg_tiles(const WGParams& p, int* bm, int* bn) {
   *bn = (p.Cs > 64) ? 128 : 64;
   *bm = (p.M > 64) ? 128 : 64;
-  const int t = veex_env_int("VEEX_WG_TILE", 0);   // tuning: 1 = 64x64, 2 = 128x64, 3 = 64x128
+  const int t = veex_tune_int("VEEX_WG_TILE", 0);   // tuning: 1 = 64x64, 2 = 128x64, 3 = 64x128
   if (t == 1) { *bm = 64; *bn = 64; }
   else if (t == 2) { *bn = 64; }
   else if (t == 3) { *bm = 64; }
@@ -411,7 +411,7 @@ template <int BM, int BN>
 static int wg_launch_cfg(const WGParams& pin, bool fast, hipStream_t st) {
   WGParams p = pin;
   p.gx = (p.M + BM - 1) / BM; p.gy = (p.Cs + BN - 1) / BN; p.gz = p.nsplit;
-  p.remap = veex_env_int("VEEX_XCD_WG", 1);   // see wgrad_gemm_v3.hip
+  p.remap = veex_tune_int("VEEX_XCD_WG", 1);   // see wgrad_gemm_v3.hip
   dim3 grid((unsigned)p.gx * p.gy * p.gz, 1, 1);
   constexpr size_t lds = 2 * VEEX_BK * ((BM + 4) + (BN + 4)) * sizeof(float);
   if (!fast) {
@@ -445,7 +445,7 @@ int veex_launch_wgrad(const WGParams& p, hipStream_t st) {
                     p.R < (1 << 24) && !(p.b_scale != nullptr && p.b_aff_spatial) &&
                     !(p.b_scale != nullptr && p.s_scale != nullptr) &&
                     (p.s_scale == nullptr || !p.s_aff_spatial || (p.s_aff_mask + 1) == p.Hs * p.Ws * p.Cs);
-  if (fast && veex_env_int("VEEX_WGV3", 1) && veex_wgrad_v3_ok(p)) return veex_launch_wgrad_v3(p, bm, bn, st);
+  if (fast && veex_tune_int("VEEX_WGV3", 1) && veex_wgrad_v3_ok(p)) return veex_launch_wgrad_v3(p, bm, bn, st);
   if (bm == 128 && bn == 128) return wg_launch_cfg<128, 128>(p, fast, st);
   if (bm == 128 && bn == 64) return wg_launch_cfg<128, 64>(p, fast, st);
   if (bm == 64 && bn == 128) return wg_launch_cfg<64, 128>(p, fast, st);

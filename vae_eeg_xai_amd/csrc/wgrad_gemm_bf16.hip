@@ -400,7 +400,7 @@ template <int BM, int BN>
 static int wgbc_launch(const WGParams& pin, hipStream_t st) {
   WGParams p = pin;
   p.gx = (p.M + BM - 1) / BM; p.gy = (p.Cs + BN - 1) / BN; p.gz = p.nsplit;
-  p.remap = veex_env_int("VEEX_XCD_WG", 1);   // -7 %: the tap tiles of one row split share their rows of `big` in one L2
+  p.remap = veex_tune_int("VEEX_XCD_WG", 1);   // -7 %: the tap tiles of one row split share their rows of `big` in one L2
   dim3 grid((unsigned)p.gx * p.gy * p.gz, 1, 1);
   constexpr size_t lds = 2 * (BM + BN) * 72 * 2 + WGBC_TABW * sizeof(int2);
   static bool attr_done = false;
@@ -419,7 +419,7 @@ template <int BM, int BN>
 static int wgb_launch(const WGParams& pin, hipStream_t st) {
   WGParams p = pin;
   p.gx = (p.M + BM - 1) / BM; p.gy = (p.Cs + BN - 1) / BN; p.gz = p.nsplit;
-  p.remap = veex_env_int("VEEX_XCD_WG", 0);
+  p.remap = veex_tune_int("VEEX_XCD_WG", 0);
   dim3 grid((unsigned)p.gx * p.gy * p.gz, 1, 1);
   constexpr size_t lds = 2 * (BM + BN) * 40 * 2;
   const bool affb = p.b_scale != nullptr, affs = p.s_scale != nullptr;

@@ -231,7 +231,7 @@ static int wg3_launch(const WGParams& pin, hipStream_t st) {
   p.gx = (p.M + BM - 1) / BM; p.gy = (p.Cs + BN - 1) / BN; p.gz = p.nsplit;
   // XCD-grouping the tap tiles of one row split (they read the same rows of `big`, shifted) cuts the HBM
   // fetches ~5x; -1 % once no CU holds a block more than the others (net.hip wgrad_split)
-  p.remap = veex_env_int("VEEX_XCD_WG", 1);
+  p.remap = veex_tune_int("VEEX_XCD_WG", 1);
   dim3 grid((unsigned)p.gx * p.gy * p.gz, 1, 1);
   const int tab_rows = (p.rows_per_split + VEEX_BK - 1) / VEEX_BK * VEEX_BK;
   const bool affb = p.b_scale != nullptr;

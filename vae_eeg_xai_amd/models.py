@@ -290,6 +290,12 @@ class VAE:
         self.optimizer = None
         self.stop_training = False
         self.grad_buckets = int(kwargs.pop("grad_buckets", 2))   # data parallelism: 2 = overlapped exchange, 1 = one all-reduce
+        # the two Keras readings nothing in the reference pins (Net.set_semantics): {"bn": "inference"|"batch",
+        # "bce": "logits"|"probs"}.  bn="batch" under data parallelism normalises each rank's slice on its own
+        # statistics, as Keras's per-replica BatchNormalization does.
+        semantics = kwargs.pop("semantics", None)
+        if semantics:
+            self._net.set_semantics(**semantics)
         self.total_loss_tracker = _Mean("total_loss", self, 0)
         self.reconstruction_loss_tracker = _Mean("reconstruction_loss", self, 1)
         self.kl_loss_tracker = _Mean("kl_loss", self, 2)
@@ -461,7 +467,7 @@ class VAE:
         graph = kwargs.get("graph", None)
         if graph is None:
             graph = net.GRAPH_MIN_BATCH <= batch_size <= net.GRAPH_MAX_BATCH
-        use_graph = bool(graph) and world == 1 and N >= batch_size
+        use_graph = bool(graph) and world == 1 and N >= batch_size and net.semantics["bn"] == "inference"
         for epoch in range(int(epochs)):
             perm = rng.permutation(N) if shuffle else np.arange(N)
             perm_d = torch.from_numpy(perm).to(net.device)

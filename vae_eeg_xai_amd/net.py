@@ -81,9 +81,10 @@ class Net:
             self.metrics = torch.zeros(4, dtype=torch.float32, device=self.device)
         self.philox_seed = 42
         self.samples_seen = 0
+        self.semantics = {"bn": "inference", "bce": "logits"}
         # the whole-step calls go through torch.ops.veex.* (ops.py: custom ops whose bodies are the ctypes
-        # calls); VEEX_DIRECT_CTYPES=1 binds the C-ABI directly (same kernels; for measuring the dispatcher)
-        self.via_ops = os.environ.get("VEEX_DIRECT_CTYPES", "0") != "1"
+        # calls); ``net.via_ops = False`` binds the C-ABI directly (same kernels; for measuring the dispatcher)
+        self.via_ops = True
         self.reset_bn_state()
 
     def __del__(self):

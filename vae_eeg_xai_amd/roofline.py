@@ -86,8 +86,8 @@ def gemm_cases(B, bf16=False):
     stream = _lib.current_stream
     keep = []
     # fp32 engine: producers write a BatchNorm-applied fp32 copy (VeexGemmDesc::out_bn) and consumers read it without an
-    # affine prologue, as the whole-step entry points do (VEEX_BNCOPY=0: consumers apply the affine, as in round 1)
-    bncopy = (not bf16) and os.environ.get("VEEX_BNCOPY", "1") != "0"
+    # affine prologue, as the whole-step entry points do
+    bncopy = not bf16
 
     def gg(label, macs, mode, A, W, out, N, Hin, Cin, Hout, Cout, k, stride, pb, aff=None, spatial=0, epi=0,
            aux=None, esc=None, wbf=None, osc=None):
@@ -209,7 +209,7 @@ def algorithmic_bytes(label, B, bf16=False):
     e = 2 if bf16 else 4                      # operand element size
     ocopy = 2 if bf16 else 0                  # extra bf16 copy of a result
     if kind == "fwd":
-        if not bf16 and layer != "dec.deconv5" and os.environ.get("VEEX_BNCOPY", "1") != "0":
+        if not bf16 and layer != "dec.deconv5":
             ocopy = 4                         # the BatchNorm-applied fp32 copy the next GEMMs read
         return n_in * e + n_w * e + n_out * (4 + ocopy)
     if kind == "dgrad":                       # reads d(out) and the activation of the layer below, writes d(in)
