@@ -214,7 +214,7 @@ def main():
                     help="local batch per GPU (default: 512 on one GPU = configs[1]; 1024 with --gpus > 1 = configs[2], "
                          "global batch 8192 on 8 GPUs)")
     ap.add_argument("--latent", type=int, default=LATENT, help="latent dimension (configs[2] sweeps 2, 8, 16, 28, 64, 128)")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--dtype", choices=["f32", "f32x3", "bf16"], default="f32",
                     help="arithmetic of the conv/deconv contractions: exact fp32 MFMA (parity path, default) or bf16 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

@@ -96,6 +96,10 @@ typedef struct VeexGemmDesc {
                               BatchNorm applied once by the producer): the fp32 GEMMs that consume the activation then
                               take it as `in` / `small` / `big` WITHOUT in_scale / in_shift -- same values bit for bit,
                               8 of 15 vector instructions less per K chunk of the consumer */
+  int32_t weight_planes;   /* 3: weight_bf16 holds the three-term bf16 split of the fp32 weights, [plane][tap][Cout][Cin]
+                              (veex_pack_weights_bf16x3): the launch computes an fp32 result -- operands split into three
+                              bf16 terms, six partial products per multiply, fp32 accumulate -- on the bf16 matrix cores
+                              (DESIGN.md 3.4).  0 / 1: weight_bf16 is the single rounded copy (bf16 engine). */
 } VeexGemmDesc;
 int veex_gather_gemm(const VeexGemmDesc* d, veexStream_t stream);
 /* bf16 copy of one layer's kernel for veex_gather_gemm: src fp32 [taps][rows][cols] ->
@@ -103,6 +107,8 @@ int veex_gather_gemm(const VeexGemmDesc* d, veexStream_t stream);
  * (kh,kw,Cin,Cout) need transpose=1 for the forward (mode 0) and 0 for the input gradient (mode 1);
  * Conv2DTranspose kernels (kh,kw,Cout,Cin) the other way round. */
 int veex_pack_weights_bf16(const float* src, void* dst, int taps, int rows, int cols, int transpose, veexStream_t s);
+/* the three-term split of the same copy: dst bf16 [3][taps][..][..], src = plane 0 + plane 1 + plane 2 to 2^-24 relative */
+int veex_pack_weights_bf16x3(const float* src, void* dst, int taps, int rows, int cols, int transpose, veexStream_t s);
 /* fp32 transposed copy of one layer's kernel: dst[tap][c][r] = src[tap][r][c] (VeexGemmDesc::weight_t) */
 int veex_transpose_weights_f32(const float* src, float* dst, int taps, int rows, int cols, veexStream_t s);
 /* rows of the partials slab an epilogue-1 launch of this descriptor writes */
@@ -267,6 +273,10 @@ long long veex_net_ws_offset(const VeexNet* net, int batch, const char* name, lo
  * fp32 accumulation, fp32 storage and fp32 master weights (north_star "fp32 reference plus bf16") */
 #define VEEX_COMPUTE_F32 0
 #define VEEX_COMPUTE_BF16 1
+/* fp32 results on the bf16 matrix cores: every operand of the large conv / deconv GEMMs is split into three bf16 terms
+ * and each product accumulated in fp32 from six partial products.  Same tolerance class as
+ * VEEX_COMPUTE_F32 (the parity tests run both at 1e-5); layers the split kernel does not win on stay on the fp32 MFMA. */
+#define VEEX_COMPUTE_F32X3 2
 int veex_net_set_compute(VeexNet* net, int compute);
 
 /* The two Keras 2.13 behaviours of models.py:152-160 that nothing in the reference tree can pin (parity unpinned;

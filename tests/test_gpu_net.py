@@ -10,9 +10,9 @@ from util import RTOL, LAYERS, alt_golden_cases, device_masks, golden_cases, rel
 pytestmark = pytest.mark.gpu
 
 
-def _net(variant, L):
+def _net(variant, L, compute="f32"):
     from vae_eeg_xai_amd.net import Net
-    return Net(L, variant)
+    return Net(L, variant, compute=compute)
 
 
 def _case(variant, L, B, seed=3, jitter=0.1):
@@ -30,17 +30,28 @@ def test_train_step_forward_loss_and_every_gradient(variant, L, B):
     _check_train_step(variant, L, B, None)
 
 
+# the split-fp32 engine (compute="f32x3": fp32 results on the bf16 matrix cores, csrc/gather_gemm_x3.hip) at the SAME
+# bar as the fp32-MFMA engine; batches from 20 up so that the split kernel takes launches (N*Hout*Wout >= 4096)
+@pytest.mark.parametrize("variant,L,B", [("vae", 28, 70), ("ae", 28, 64), ("vae", 8, 200), ("vae", 28, 4)])
+def test_split_fp32_engine_train_step_at_the_fp32_tolerance(variant, L, B):
+    _check_train_step(variant, L, B, None, compute="f32x3")
+
+
+def test_split_fp32_engine_with_batch_statistics():
+    _check_train_step("vae", 28, 70, {"bn": "batch"}, BN_BATCH_BTOL, compute="f32x3")
+
+
 # Batch-statistics BatchNorm divides by the batch's own sigma (down to sqrt(1e-3)) and differentiates through it: the
 # float64 oracle's OWN answer moves by 1.3e-5 (dlogits) .. 4e-4 (conv1 kernel gradient at B=70) when its weights are
 # perturbed by half an fp32 ulp, 60x more than under moving statistics, so the backward bound is wider in that mode.
 BN_BATCH_BTOL = 3e-4
 
 
-def _check_train_step(variant, L, B, sem, btol=RTOL):
+def _check_train_step(variant, L, B, sem, btol=RTOL, compute="f32"):
     import torch
     p, x, eps = _case(variant, L, B)
     c = vo.forward(p, x, eps, variant, sem)
-    net = _net(variant, L)
+    net = _net(variant, L, compute)
     net.set_weights_dict(p)
     if sem is not None:
         net.set_semantics(**sem)

@@ -33,7 +33,7 @@ class GemmDesc(C.Structure):
         ("epilogue", C.c_int32), ("relu", C.c_int32), ("e_channels", C.c_int32), ("nsplit", C.c_int32),
         ("in_bf16", C.c_void_p), ("out_bf16", C.c_void_p), ("out_scale", C.c_void_p), ("out_shift", C.c_void_p),
         ("out_channels", C.c_int32), ("struct_size", C.c_int32),
-        ("weight_bf16", C.c_void_p), ("weight_t", C.c_void_p), ("out_bn", C.c_void_p),
+        ("weight_bf16", C.c_void_p), ("weight_t", C.c_void_p), ("out_bn", C.c_void_p), ("weight_planes", C.c_int32),
     ]
 
 
@@ -77,6 +77,7 @@ SIGNATURES = {
     "veex_deconv6_bce_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P]),
     "veex_deconv6_bce_fwd_form": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _I, _P]),
     "veex_net_set_semantics": (_I, [_P, _I, _I]),
+    "veex_pack_weights_bf16x3": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "veex_net_set_sample_counter": (_I, [_P, _P]),
     "veex_net_set_bucket_event": (_I, [_P, _P]),
     "veex_net_grad_bucket": (_I, [_P, C.POINTER(_L), C.POINTER(_L)]),
@@ -122,7 +123,7 @@ ABI_VERSION = 3               # VEEX_ABI_VERSION of include/veex.h
 F_PHILOX = 1
 F_ZMEAN_DECODE = 2
 VARIANT_VAE, VARIANT_AE = 0, 1
-COMPUTE_F32, COMPUTE_BF16 = 0, 1
+COMPUTE_F32, COMPUTE_BF16, COMPUTE_F32X3 = 0, 1, 2
 
 
 def _load():

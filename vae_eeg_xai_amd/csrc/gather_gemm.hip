@@ -550,14 +550,17 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(const GGParams p) {
 // engine keeps 128-row tiles for forward launches (operand re-use matters at 16x the MFMA rate) and
 // takes 64x64 for the heavier BatchNorm/ReLU-backward epilogue and for launches of < 256 blocks.
 static bool gg_fast_ok_fwd(const GGParams& p);
+static bool gg_x3_dispatch(const GGParams& p, bool fast);
 int veex_gg_bm(const GGParams& p) {
   const long long M = (long long)p.Nb * p.Hout * p.Wout;
+  if (gg_x3_dispatch(p, gg_fast_ok_fwd(p))) return veex_gg_x3_bm(p);
   if (veex_gg_v4_ok(p)) return 32;   // small launches: 32x32 tiles, K split over the waves of a block (gather_gemm_v4.hip)
   if (M < 4096) return 64;
   const int force = veex_tune_int("VEEX_BM", 0);
   if (force == 64 || force == 128) return force;
-  if (p.Wbf == nullptr && veex_env_int("VEEX_GGV3", 1) && gg_fast_ok_fwd(p) && veex_gg_v3_ok(p)) return veex_gg_v3_bm(p);   // lean fp32 kernel
-  if (p.Wbf == nullptr || p.Cin % 32 != 0) return 64;
+  const bool nobf = p.Wbf == nullptr || p.wplanes == 3;   // (a split-fp32 launch the split kernel does not take runs on the fp32 kernels)
+  if (nobf && veex_env_int("VEEX_GGV3", 1) && gg_fast_ok_fwd(p) && veex_gg_v3_ok(p)) return veex_gg_v3_bm(p);   // lean fp32 kernel
+  if (nobf || p.Cin % 32 != 0) return 64;
   const long long blocks = ((M + 127) / 128) * ((p.Cout > 64) ? (p.Cout + 127) / 128 : 1);
   // BatchNorm/ReLU-backward epilogue: 64-row tiles, except the stride-1 multi-tap input gradients (deconv2, deconv4:
   // long K loops), where 128-row tiles measure -10..-27 % since the epilogue went branch-free
@@ -693,9 +696,14 @@ static bool gg_fast_ok(const GGParams& p) {
          (p.a_scale == nullptr || !p.aff_spatial || (p.aff_mask + 1) == p.Hin * p.Win * p.Cin);
 }
 // the launch goes to the bf16 engine (gather_gemm_bf16.hip)
+static bool gg_x3_dispatch(const GGParams& p, bool fast) {
+  const long long Mtot = (long long)p.Nb * p.Hout * p.Wout;
+  return p.Wbf != nullptr && p.wplanes == 3 && fast && Mtot >= 4096 && Mtot < (1LL << 24) && Mtot * p.Cout * 4 < 0x7FFF0000LL && p.Cin % 32 == 0 &&
+         p.Abf == nullptr && p.OutBf == nullptr && veex_gg_x3_cfg(p) >= 0;
+}
 static bool gg_bf16_dispatch(const GGParams& p, bool fast) {
   const long long Mtot = (long long)p.Nb * p.Hout * p.Wout;
-  return p.Wbf != nullptr && fast && Mtot >= 4096 && Mtot < (1LL << 24) && Mtot * p.Cout * 4 < 0x7FFF0000LL && p.Cin % 32 == 0;
+  return p.Wbf != nullptr && p.wplanes != 3 && fast && Mtot >= 4096 && Mtot < (1LL << 24) && Mtot * p.Cout * 4 < 0x7FFF0000LL && p.Cin % 32 == 0;
 }
 // 1 if this launch would run on the bf16 engine reading only the bf16 copy of its A operand (then nobody reads the
 // fp32 A), and 2 if in addition it can write its bf16 output copy alone (Out may be null)
@@ -731,6 +739,7 @@ int veex_launch_gather_gemm(const GGParams& pin, hipStream_t st) {
   const int bm = veex_gg_bm(p);
   const int bn = gg_bn(p.Cout, bm);
   const bool fast = gg_fast_ok(p);
+  if (gg_x3_dispatch(p, fast)) return veex_launch_gather_gemm_x3(p, mtiles, st);
   if (gg_halo_dispatch(p)) return veex_launch_halo_gemm_bf16(p, st);
   if (gg_bf16_dispatch(p, fast)) return veex_launch_gather_gemm_bf16(p, mtiles, st);
   if (p.Out == nullptr) { veex_set_error("gather_gemm: null output (only the bf16 engine can write the bf16 copy alone)"); return -1; }

@@ -241,6 +241,9 @@ __device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned off)
 
 // launch-side helpers shared by the fp32 and bf16 engines
 int veex_launch_gather_gemm_bf16(GGParams& p, int mtiles, hipStream_t st);   // gather_gemm_bf16.hip
+int veex_gg_x3_cfg(const GGParams& p);                                         // -1: the split kernel does not take the launch
+int veex_gg_x3_bm(const GGParams& p);                                          // gather_gemm_x3.hip
+int veex_launch_gather_gemm_x3(GGParams& p, int mtiles, hipStream_t st);
 int veex_hg_ok(const GGParams& p);                                             // halo_gemm_bf16.hip: the halo-tile kernel takes it
 int veex_hg_m_tiles(const GGParams& p);                                        // rows of its partials slab (sample groups x phases)
 int veex_launch_halo_gemm_bf16(GGParams& p, hipStream_t st);

@@ -75,7 +75,9 @@ static int fill_gg(const VeexGemmDesc* d, GGParams& p) {
   const bool has_wbf = have >= offsetof(VeexGemmDesc, weight_bf16) + sizeof(void*);
   const bool has_wt = have >= offsetof(VeexGemmDesc, weight_t) + sizeof(void*);
   const bool has_obn = have >= offsetof(VeexGemmDesc, out_bn) + sizeof(void*);
+  const bool has_wpl = have >= offsetof(VeexGemmDesc, weight_planes) + sizeof(int32_t);
   p.A = d->in; p.W = d->weight; p.Wbf = has_wbf ? d->weight_bf16 : nullptr; p.Wt = (has_wt && d->mode == 0) ? d->weight_t : nullptr; p.Out = d->out;
+  p.wplanes = has_wpl ? d->weight_planes : 0;
   p.Abf = d->in_bf16; p.OutBf = d->out_bf16; p.o_scale = d->out_scale; p.o_shift = d->out_shift;
   p.OutBn = (has_obn && d->epilogue == VEEX_EPI_FWD) ? d->out_bn : nullptr;
   if (p.OutBn != nullptr && p.o_scale == nullptr) { veex_set_error("gather_gemm: out_bn needs out_scale / out_shift"); return VEEX_EINVAL; }
@@ -359,8 +361,8 @@ extern "C" int veex_net_set_side_stream(VeexNet* n, veexStream_t side) {
   return 0;
 }
 extern "C" int veex_net_set_compute(VeexNet* n, int compute) {
-  if (n == nullptr || (compute != VEEX_COMPUTE_F32 && compute != VEEX_COMPUTE_BF16)) { veex_set_error("set_compute: bad arguments"); return VEEX_EINVAL; }
-  if (compute != VEEX_COMPUTE_F32 && n->bn_mode == VEEX_BN_BATCH) { veex_set_error("set_compute: batch-statistics BatchNorm runs on the fp32 engine only"); return VEEX_EINVAL; }
+  if (n == nullptr || (compute != VEEX_COMPUTE_F32 && compute != VEEX_COMPUTE_BF16 && compute != VEEX_COMPUTE_F32X3)) { veex_set_error("set_compute: bad arguments"); return VEEX_EINVAL; }
+  if (compute == VEEX_COMPUTE_BF16 && n->bn_mode == VEEX_BN_BATCH) { veex_set_error("set_compute: batch-statistics BatchNorm runs on the fp32 engine only"); return VEEX_EINVAL; }
   n->compute = compute;
   return 0;
 }
@@ -368,7 +370,7 @@ extern "C" int veex_net_set_semantics(VeexNet* n, int bn_mode, int bce_form) {
   if (n == nullptr || (bn_mode != VEEX_BN_INFERENCE && bn_mode != VEEX_BN_BATCH) || (bce_form != VEEX_BCE_LOGITS && bce_form != VEEX_BCE_PROBS)) {
     veex_set_error("set_semantics: bad arguments"); return VEEX_EINVAL;
   }
-  if (bn_mode == VEEX_BN_BATCH && n->compute != VEEX_COMPUTE_F32) { veex_set_error("set_semantics: batch-statistics BatchNorm runs on the fp32 engine only"); return VEEX_EINVAL; }
+  if (bn_mode == VEEX_BN_BATCH && n->compute == VEEX_COMPUTE_BF16) { veex_set_error("set_semantics: batch-statistics BatchNorm runs on the fp32 engine only"); return VEEX_EINVAL; }
   n->bn_mode = bn_mode; n->bce_form = bce_form;
   return 0;
 }
@@ -624,8 +626,9 @@ static void make_plan(const VeexNet* n, int B, Plan& P) {
   for (int i = 0; i < 7; ++i) {
     const ConvLayer& l = big_layer(n, i);
     const long long halfs = (long long)l.k * l.k * l.Cin * l.Cout;
-    P.wpack[i][0] = w.add(std::string("wpack.") + l.name + ".a", (halfs + 1) / 2);
-    P.wpack[i][1] = w.add(std::string("wpack.") + l.name + ".t", (halfs + 1) / 2);
+    const long long planes = (n->compute == VEEX_COMPUTE_F32X3) ? 3 : 1;   // split-fp32: three bf16 planes per packed copy
+    P.wpack[i][0] = w.add(std::string("wpack.") + l.name + ".a", (planes * halfs + 1) / 2);
+    P.wpack[i][1] = w.add(std::string("wpack.") + l.name + ".t", (planes * halfs + 1) / 2);
     P.wpackf[i] = w.add(std::string("wpackf.") + l.name, halfs);
   }
 }
@@ -703,8 +706,10 @@ static const float* packed_wt(const Ctx& c, int i) {
   return ((i < 2) ? c.have_wt_enc : c.have_wt_bwd) ? c.ws + c.plan.wpackf[i] : nullptr;
 }
 
+int veex_pack_weights_bf16x3_multi(int n, const float* const* src, void* const* dst, const int* taps, const int* rows,
+                                   const int* cols, const int* transpose, hipStream_t st);   // gather_gemm_x3.hip
 static int run_pack_weights(Ctx& c) {
-  if (c.n->compute != VEEX_COMPUTE_BF16) return 0;
+  if (c.n->compute != VEEX_COMPUTE_BF16 && c.n->compute != VEEX_COMPUTE_F32X3) return 0;
   const float* src[14]; void* dst[14]; int taps[14], rows[14], cols[14], tr[14];
   for (int i = 0; i < 7; ++i) {
     const ConvLayer& l = big_layer(c.n, i);
@@ -715,11 +720,12 @@ static int run_pack_weights(Ctx& c) {
       rows[k] = (i < 2) ? l.Cin : l.Cout; cols[k] = (i < 2) ? l.Cout : l.Cin; tr[k] = t;
     }
   }
+  if (c.n->compute == VEEX_COMPUTE_F32X3) return veex_pack_weights_bf16x3_multi(14, src, dst, taps, rows, cols, tr, c.st);
   return veex_pack_weights_bf16_multi(14, src, dst, taps, rows, cols, tr, c.st);
 }
 // packed weights [tap][Cout_gemm][Cin_gemm] for the forward (fwd=1) or input-gradient GEMM of big layer i
 static const void* packed_w(const Ctx& c, int i, int fwd) {
-  if (c.n->compute != VEEX_COMPUTE_BF16) return nullptr;
+  if (c.n->compute != VEEX_COMPUTE_BF16 && c.n->compute != VEEX_COMPUTE_F32X3) return nullptr;
   const int conv = (i < 2);
   const int which = (conv == (fwd != 0)) ? 1 : 0;   // conv fwd / deconv dgrad: transposed copy
   return c.ws + c.plan.wpack[i][which];
@@ -763,6 +769,7 @@ static int fwd_gemm(Ctx& c, const ConvLayer& l, int mode, const float* in, int i
                     const float* wt = nullptr, const float* in_bncopy = nullptr, float* out_bncopy = nullptr) {
   GGParams p; memset(&p, 0, sizeof(p));
   p.A = in; p.W = c.P + l.w; p.Wbf = wp; p.Wt = wt; p.Out = out; p.bias = c.P + l.b;
+  p.wplanes = (c.n->compute == VEEX_COMPUTE_F32X3) ? 3 : 0;
   p.Abf = abf; p.OutBf = outbf;
   if (l.bn >= 0) p.OutBn = out_bncopy;
   if ((outbf != nullptr || p.OutBn != nullptr) && l.bn >= 0) { p.o_scale = c.scale(l.bn); p.o_shift = c.shift(l.bn); p.o_cmask = l.bnC - 1; }
@@ -911,6 +918,7 @@ static void deconv_dgrad_desc(Ctx& c, int i, GGParams& p) {
   const ConvLayer& l = n->dc[i];
   memset(&p, 0, sizeof(p));
   p.A = c.ws + P.d_dc[i]; p.W = c.P + l.w; p.Wbf = packed_w(c, i + 2, 0); p.Wt = packed_wt(c, i + 2);
+  p.wplanes = (c.n->compute == VEEX_COMPUTE_F32X3) ? 3 : 0;
   p.Abf = bfp(c, P.bf_d_dc[i]); p.OutBf = (i > 0) ? bfp(c, P.bf_d_dc[i - 1]) : nullptr;
   p.Nb = c.B; p.Hin = p.Win = l.Hout; p.Cin = l.Cout; p.Hout = p.Wout = l.Hin; p.Cout = l.Cin;
   p.kh = p.kw = l.k; p.stride = l.stride; p.pb = l.pb; p.mode = 0;
@@ -1018,6 +1026,7 @@ static int encoder_backward(Ctx& c, const float* x, float* G, int want_param_gra
     }
     GGParams p; memset(&p, 0, sizeof(p));
     p.A = ws + P.d_conv[i]; p.W = c.P + l.w; p.Wbf = packed_w(c, i - 1, 0);
+    p.wplanes = (c.n->compute == VEEX_COMPUTE_F32X3) ? 3 : 0;
     p.Abf = bfp(c, P.bf_d_conv[i]); p.OutBf = (i == 2) ? bfp(c, P.bf_d_conv[1]) : nullptr;
     p.Nb = c.B; p.Hin = p.Win = l.Hout; p.Cin = l.Cout; p.Hout = p.Wout = l.Hin; p.Cout = l.Cin;
     p.kh = p.kw = 3; p.stride = 2; p.pb = l.pb; p.mode = 1;

@@ -21,6 +21,8 @@ struct GGParams {
   const float* A;        // gathered operand, NHWC [Nb][Hin][Win][Cin]
   const float* W;
   const void* Wbf;        // optional packed bf16 weights [tap][Cout][Cin]: run the bf16-MFMA kernel
+  int wplanes;            // 3: Wbf holds the three-term split [plane][tap][Cout][Cin] of the fp32 weights: run the
+                          // split-fp32 kernel (gather_gemm_x3.hip: fp32 result on the bf16 matrix cores); else 0 / 1
   const float* Wt;        // optional fp32 copy of W as [tap][Cout][Cin] for a MODE 0 launch of the lean fp32 kernel (whose
                           // B fragment then is one 16-byte LDS read per four MFMAs, like mode 1, instead of four 4-byte ones)
   float* Out;            // NHWC [Nb][Hout][Wout][Cout]; RAW: slab base [nsplit][same]

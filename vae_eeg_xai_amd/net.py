@@ -96,12 +96,14 @@ class Net:
     def set_compute(self, compute: str):
         """Arithmetic of the seven MFMA-bound conv / deconv layers (forward, input and weight
         gradients): "f32" = exact fp32 MFMA (parity path), "bf16" = bf16 MFMA with fp32 accumulation,
-        fp32 activations in HBM and fp32 master weights.  Layers too small for a 128-row tile
-        (N*Hout*Wout < 4096) stay on the fp32 kernels."""
-        if compute not in ("f32", "bf16"):
-            raise ValueError("compute must be 'f32' or 'bf16'")
-        check(lib.veex_net_set_compute(self._h, _lib.COMPUTE_BF16 if compute == "bf16" else _lib.COMPUTE_F32),
-              "net_set_compute")
+        fp32 activations in HBM and fp32 master weights; "f32x3" = fp32 results on the bf16 matrix cores (operands
+        split into three bf16 terms, six partial products per multiply, fp32 accumulate: the same 1e-5 parity bar as
+        "f32", csrc/gather_gemm_x3.hip).  Layers too small for a 128-row tile (N*Hout*Wout < 4096) stay on the fp32
+        kernels."""
+        codes = {"f32": _lib.COMPUTE_F32, "bf16": _lib.COMPUTE_BF16, "f32x3": _lib.COMPUTE_F32X3}
+        if compute not in codes:
+            raise ValueError("compute must be 'f32', 'f32x3' or 'bf16'")
+        check(lib.veex_net_set_compute(self._h, codes[compute]), "net_set_compute")
         self.compute = compute
         self._drop_workspaces()     # the workspace plan (split-K slabs) depends on the kernel family
 

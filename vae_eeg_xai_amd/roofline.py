@@ -130,7 +130,7 @@ def gemm_cases(B, bf16=False):
             mt = (N * Hout * Hout + 31) // 32 + 4
             assert lib.veex_gather_gemm_m_tiles(C.byref(d)) <= mt
             part = torch.empty(mt * 3 * Cout, device="cuda"); keep.append(part); d.partials = part.data_ptr()
-        keep.extend([A, W, out, d])
+        keep.extend([A, W, out, d, aff, esc, aux])   # (everything a descriptor points to must outlive gemm_cases)
         return label, macs, (lambda d=d: check(lib.veex_gather_gemm(C.byref(d), stream()), label))
 
     def wg(label, macs, big, small, N, Hb, Cb, Hs, Cs, k, stride, pb, aff_small=None, aff_big=None):
@@ -157,7 +157,7 @@ def gemm_cases(B, bf16=False):
         d.nsplit, d.rows_per_split = ns.value, per.value
         out = torch.empty(d.nsplit * M * Cs, device="cuda")
         d.out = out.data_ptr()
-        keep.extend([big, small, out, d])
+        keep.extend([big, small, out, d, aff_small, aff_big])
         return label, macs, (lambda d=d: check(lib.veex_wgrad_gemm(C.byref(d), stream()), label))
 
     cases = []
