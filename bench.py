@@ -147,16 +147,17 @@ def attribution_bench(net, x_all, world, latent, iters=8, warmup=2):
             f"all{latent}": out["all"], "sharding": "inputs split across ranks, replicas only"}
 
 
-def bf16_leg(x_all, B, L, world, rank, steps, warmup):
-    """configs[1] names "fp32 and bf16 MFMA": the same train step on the bf16 engine (bf16 MFMA, fp32 accumulation,
-    fp32 master weights), timed like the headline loop on the same resident data.  fp32 stays the headline `value`
-    (only it meets the 1e-5 parity bar); this object rides beside `attribution`."""
+def engine_leg(compute, x_all, B, L, world, rank, steps, warmup):
+    """The same train step on another engine, timed like the headline loop on the same resident data; the object rides
+    beside `attribution`.  "bf16": configs[1] names "fp32 and bf16 MFMA" -- bf16 MFMA, fp32 accumulation, fp32 master
+    weights, its own stated tolerance.  "f32": the fp32-MFMA engine (v_mfma_f32_32x32x2_f32 everywhere), the engine of
+    the round-1/2 headline, which meets the same 1e-5 parity bar as the split-fp32 engine behind `value`."""
     import torch
     import torch.distributed as dist
     from vae_eeg_xai_amd.net import Net
     from vae_eeg_xai_amd import roofline as rl
     from vae_eeg_xai_amd import dist as vdist
-    net = Net(L, "vae", compute="bf16")
+    net = Net(L, "vae", compute=compute)
     net.init_weights(seed=42)
     nb = x_all.shape[0] // B
 
@@ -186,6 +187,14 @@ def bf16_leg(x_all, B, L, world, rank, steps, warmup):
     if rank != 0:
         return None
     sps = steps * B * world / dt
+    if compute == "f32":
+        out = {"metric": "VAE train samples/sec, fp32-MFMA engine", "value": sps, "unit": "samples/s", "ms_per_step": 1e3 * dt / steps,
+               "steps": steps, "warmup": warmup, "dtype": "f32", "train_tflops": sps * train_macs(L) * 2 / 1e12,
+               "frac_f32_mfma_peak": sps * train_macs(L) * 2 / 1e12 / (PEAK_F32_MFMA_TFLOPS * world),
+               "final_loss": float(net.grads[net.n_params].item()) / world,
+               "tolerance": "1e-5 of the tensor's max-abs against the float64 oracle (tests/test_gpu_net.py), as the headline engine"}
+        out["roofline"] = rl.dominant_kernel_roofline(net, B)
+        return out
     out = {"metric": "VAE train samples/sec, bf16 MFMA engine", "value": sps, "unit": "samples/s", "ms_per_step": 1e3 * dt / steps,
            "steps": steps, "warmup": warmup, "dtype": "bf16",
            "train_tflops": sps * train_macs(L) * 2 / 1e12,
@@ -214,15 +223,17 @@ def main():
                     help="local batch per GPU (default: 512 on one GPU = configs[1]; 1024 with --gpus > 1 = configs[2], "
                          "global batch 8192 on 8 GPUs)")
     ap.add_argument("--latent", type=int, default=LATENT, help="latent dimension (configs[2] sweeps 2, 8, 16, 28, 64, 128)")
-    ap.add_argument("--dtype", choices=["f32", "f32x3", "bf16"], default="f32",
-                    help="arithmetic of the conv/deconv contractions: exact fp32 MFMA (parity path, default) or bf16 MFMA")
+    ap.add_argument("--dtype", choices=["f32", "f32x3", "bf16"], default="f32x3",
+                    help="engine of the conv/deconv contractions: f32x3 = fp32 results on the bf16 matrix cores (three-term "
+                         "operand split, six partial products, fp32 accumulate; default, 1e-5 parity), f32 = fp32 MFMA "
+                         "instructions everywhere (1e-5 parity), bf16 = bf16 MFMA on rounded operands (own tolerance)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-attribution", action="store_true")
     ap.add_argument("--buckets", type=int, choices=[1, 2], default=2,
                     help="N > 1: 2 = decoder gradients all-reduced on a communication stream while the encoder's backward "
                          "pass runs (dist.TwoBucketReducer), 1 = one all-reduce after the backward pass")
-    ap.add_argument("--no-bf16", action="store_true", help="skip the bf16-engine leg (the `bf16` object of the JSON line)")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the other engines' legs (the `bf16` and `f32_mfma` objects of the JSON line)")
     args = ap.parse_args()
 
     import torch
@@ -315,17 +326,20 @@ def main():
     if red is not None:
         red.close()
     attr = None if args.no_attribution else attribution_bench(net, x_all, world, L)
-    bf16 = None
-    if args.dtype == "f32" and not args.no_bf16:
+    bf16 = f32_mfma = None
+    if args.dtype != "bf16" and not args.no_bf16:
         note("bf16 leg")
-        bf16 = bf16_leg(x_all, B, L, world, rank, args.steps, args.warmup)
+        bf16 = engine_leg("bf16", x_all, B, L, world, rank, args.steps, args.warmup)
+        if args.dtype == "f32x3":
+            note("fp32-MFMA leg")
+            f32_mfma = engine_leg("f32", x_all, B, L, world, rank, args.steps, args.warmup)
 
     if rank == 0:
         sps = args.steps * B * world / dt
         out = {
             "metric": "VAE train samples/sec", "value": sps, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32",
             "data": "synthetic",
             "config": {"workload": (f"configs[1]: models.py VAE train_step, 100k synthetic 40x40 topomaps, batch {B}/GPU, "
                                     if world == 1 else
@@ -333,12 +347,16 @@ def main():
                                     f"({B}/GPU x {world} GPUs; 8192 on 8), one RCCL all-reduce of the flat gradient "
                                     f"buffer per step, {n_local} synthetic 40x40 topomaps resident per GPU, ") +
                                    f"latent {L}, Adam lr 1e-5, " +
-                                   ("fp32 (exact-f32 MFMA)" if args.dtype == "f32" else
-                                    "bf16 MFMA (fp32 accumulate / storage / master weights)"),
+                                   {"f32": "fp32 (fp32 MFMA instructions)",
+                                    "f32x3": "fp32 results, split-fp32 engine: the conv / deconv forward and input-gradient GEMMs "
+                                             "on the bf16 matrix cores from three-term operand splits (six partial products, fp32 "
+                                             "accumulate), weight gradients and small layers on the fp32 MFMA; 1e-5 parity bar",
+                                    "bf16": "bf16 MFMA (fp32 accumulate / storage / master weights)"}[args.dtype],
+                       "engine": args.dtype,
                        "global_batch": B * world, "local_batch": B, "latent": L, "parallelism": f"dp{world}",
                        "final_loss": loss},
             "train_tflops": sps * TRAIN_MACS * 2 / 1e12,
-            "frac_mfma_peak": sps * TRAIN_MACS * 2 / 1e12 / ((PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else 2500.0) * world),
+            "frac_mfma_peak": sps * TRAIN_MACS * 2 / 1e12 / ((2500.0 if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS) * world),
         }
         if local_ms is not None:
             out["local_step_ms_without_allreduce"] = local_ms
@@ -351,6 +369,11 @@ def main():
             out["attribution"] = attr
         if bf16 is not None:
             out["bf16"] = bf16
+        if f32_mfma is not None:
+            out["f32_mfma"] = f32_mfma
+        if args.dtype == "f32x3":
+            out["frac_mfma_peak_note"] = ("fp32 FLOP of the step / 157.3 TFLOP/s, the fp32 MFMA instruction's peak; 12 of the 21 large "
+                                          "GEMM launches run on the bf16 pipe instead (roofline.peak_note)")
         if not args.no_roofline:
             out["roofline"] = rl.dominant_kernel_roofline(net, B)
         if world == 1 and not args.no_cpu_baseline:

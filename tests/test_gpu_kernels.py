@@ -247,3 +247,44 @@ def test_small_launch_kernel_matches_the_64x64_kernel(case):
         assert m1 >= m0                                    # 32-row tiles: at least as many partial rows
         t0, t1 = p0.view(m0, 3, Cout).sum(0), p1.view(m1, 3, Cout).sum(0)
         assert float((t0 - t1).abs().max()) <= 1e-5 * float(t0.abs().max())
+
+
+@pytest.mark.parametrize("B", [64, 512])
+def test_split_fp32_gather_kernel_equals_the_fp32_mfma_kernel(B):
+    """VeexGemmDesc::weight_planes = 3 (gather_gemm_x3.hip): every forward / input-gradient launch of the train step
+    on the bf16 matrix cores from three-term operand splits against the same launch on the fp32 MFMA -- an fp32 result:
+    the two differ by accumulation order only (<= 5e-6 of the tensor's max-abs; a bf16 launch differs by ~4e-3)."""
+    import ctypes as C
+    import torch
+    from vae_eeg_xai_amd import _lib, roofline as rl
+    from vae_eeg_xai_amd._lib import GemmDesc, check, lib
+    took = 0
+    f32 = {label: fn for label, _, fn in rl.gemm_cases(B, False) if not label.endswith("wgrad")}
+    keep32 = rl.gemm_cases._keep
+    for label, _, fn in rl.gemm_cases(B, False, x3=True):
+        if label.endswith("wgrad"):
+            continue
+        d3 = fn.__defaults__[0]
+        d = GemmDesc.from_buffer_copy(d3)          # the same operands through the fp32-MFMA kernel
+        d.weight_bf16, d.weight_planes = None, 0
+        shape = (d.N, d.Hout, d.Wout, d.Cout)
+        ref, out = torch.empty(shape, device="cuda"), torch.full(shape, 7.0, device="cuda")
+        d.out, d3.out = ref.data_ptr(), out.data_ptr()
+        part = part3 = None
+        if d.epilogue == 1:
+            rows = d.N * d.Hout * d.Wout // 32 + 8
+            part, part3 = torch.zeros(rows * 3 * d.Cout, device="cuda"), torch.zeros(rows * 3 * d.Cout, device="cuda")
+            d.partials, d3.partials = part.data_ptr(), part3.data_ptr()
+        check(lib.veex_gather_gemm(C.byref(d), _lib.current_stream()), label)
+        check(lib.veex_gather_gemm(C.byref(d3), _lib.current_stream()), label)
+        torch.cuda.synchronize()
+        scale = ref.abs().max().item()
+        assert scale > 0 and bool(torch.isfinite(out).all())
+        assert (out - ref).abs().max().item() <= 5e-6 * scale, label
+        if d.epilogue == 1:     # column sums behind the bias / gamma / beta gradients (tile heights differ: compare totals)
+            mt, mt3 = lib.veex_gather_gemm_m_tiles(C.byref(d)), lib.veex_gather_gemm_m_tiles(C.byref(d3))
+            t, t3 = part[:mt * 3 * d.Cout].view(mt, 3, d.Cout).sum(0), part3[:mt3 * 3 * d.Cout].view(mt3, 3, d.Cout).sum(0)
+            assert (t - t3).abs().max().item() <= 2e-5 * t.abs().max().item(), label
+            took += mt3 != mt
+    del f32, keep32
+    assert B < 512 or took >= 3        # at batch 512 the split kernel's own (taller) tiles ran

@@ -7,7 +7,8 @@ from vae_eeg_xai_amd import roofline as rl
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-cases = rl.gemm_cases(B, bf16=(len(sys.argv) > 3 and sys.argv[3] == "bf16"))
+eng = sys.argv[3] if len(sys.argv) > 3 else "f32"      # f32 | f32x3 | bf16
+cases = rl.gemm_cases(B, bf16=(eng == "bf16"), x3=(eng == "f32x3"))
 for label, macs, fn in cases:
     for _ in range(reps):
         fn()

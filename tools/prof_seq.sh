@@ -6,7 +6,7 @@ export TMPDIR=/tmp VEEX_OVERLAP=0
 T=${1:-seq}; shift
 O=gpurun_out/$T
 mkdir -p $O
-timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-attribution "$@" > $O/trace.log 2>&1 || { tail $O/trace.log; exit 1; }
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-attribution --no-bf16 "$@" > $O/trace.log 2>&1 || { tail $O/trace.log; exit 1; }
 python - "$O" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/trace/**/*kernel_stats.csv", recursive=True)[0]

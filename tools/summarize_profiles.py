@@ -21,7 +21,7 @@ for extra in ("bench_bf16.json", "layer_table_bf16.txt", "hbm_table.txt", "dp2_r
 ks = newest(f"{src}/trace/*/*kernel_stats.csv")
 shutil.copy(ks, f"{dst}/{R}_kernel_stats.csv")
 with open(f"{dst}/{R}_kernel_stats.txt", "w") as f:
-    f.write("rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-attribution\n")
+    f.write("rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-attribution --no-bf16   (the default engine: split-fp32)\n")
     for r in csv.DictReader(open(ks)):
         f.write(f"{r['Name'][:100]:100s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs']) / 1e3:9.1f} pct={float(r['Percentage']):6.2f}\n")
 
@@ -63,38 +63,56 @@ def per_dispatch(path):
     return [(k, v) for k, v in d.items() if "gather_gemm" in k[1] or "wgrad_" in k[1]]
 
 
-order = open(f"{src}/pmc_fetch.log").read().split("launch order:")[1].split()[0].split(",")
-f_ = per_dispatch(newest(f"{src}/pmc_fetch/*/*counter_collection.csv"))
-w_ = per_dispatch(newest(f"{src}/pmc_write/*/*counter_collection.csv"))
-s_ = per_dispatch(newest(f"{src}/pmc_sq/*/*counter_collection.csv"))
-reps = len(f_) // len(order)
-out = {}
-with open(f"{dst}/{R}_pmc_gemms.txt", "w") as f:
-    f.write("separate rocprofv3 --pmc passes over tools/prof_gemms.py 512 (last repetition of each launch)\n"
-            "hbm_read = FETCH_SIZE KB * 1024 * 2 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM); "
-            "hbm_write = WRITE_SIZE KB * 1024; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 256 CU * 4 SIMD)\n")
-    for i, name in enumerate(order):
-        j = reps * i + reps - 1
-        fe, wr, sq = f_[j][1]["FETCH_SIZE"] * 1024 * 2, w_[j][1]["WRITE_SIZE"] * 1024, s_[j][1]
-        gui = sq["GRBM_GUI_ACTIVE"] / 8
-        util = sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 256 * 4)
-        out[name] = {"kernel": f_[j][0][1], "hbm_read_bytes": fe, "hbm_write_bytes": wr, "mfma_util": util,
-                     "gui_cycles": gui, "wait_any": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
-                     "wait_inst": sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"]}
-        f.write(f"{name:20s} hbm_read={fe / 1e6:8.1f} MB hbm_write={wr / 1e6:8.1f} MB mfma_util={util:.3f} "
-                f"gui_cycles={gui:.4g} wait_any={out[name]['wait_any']:.2f} wait_inst={out[name]['wait_inst']:.2f}  {f_[j][0][1][:70]}\n")
-json.dump(out, open(f"{dst}/{R}_pmc_gemms.json", "w"), indent=1)
-print(open(f"{dst}/{R}_pmc_gemms.txt").read())
+def pmc_summary(sfx, what):
+    """gpurun_out/<R>/pmc_{fetch,write,sq}<sfx> -> profiles/<R>_pmc_gemms<sfx>.{txt,json}; returns the per-launch dict"""
+    if not os.path.exists(f"{src}/pmc_fetch{sfx}.log"):
+        return {}
+    order = open(f"{src}/pmc_fetch{sfx}.log").read().split("launch order:")[1].split()[0].split(",")
+    f_ = per_dispatch(newest(f"{src}/pmc_fetch{sfx}/*/*counter_collection.csv"))
+    w_ = per_dispatch(newest(f"{src}/pmc_write{sfx}/*/*counter_collection.csv"))
+    s_ = per_dispatch(newest(f"{src}/pmc_sq{sfx}/*/*counter_collection.csv"))
+    reps = len(f_) // len(order)
+    out = {}
+    with open(f"{dst}/{R}_pmc_gemms{sfx}.txt", "w") as f:
+        f.write(f"{what}: separate rocprofv3 --pmc passes over tools/prof_gemms.py 512 2 (last repetition of each launch)\n"
+                "hbm_read = FETCH_SIZE KB * 1024 * 2 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM); "
+                "hbm_write = WRITE_SIZE KB * 1024; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 256 CU * 4 SIMD)\n")
+        for i, name in enumerate(order):
+            j = reps * i + reps - 1
+            fe, wr, sq = f_[j][1]["FETCH_SIZE"] * 1024 * 2, w_[j][1]["WRITE_SIZE"] * 1024, s_[j][1]
+            gui = sq["GRBM_GUI_ACTIVE"] / 8
+            util = sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 256 * 4)
+            out[name] = {"kernel": f_[j][0][1], "hbm_read_bytes": fe, "hbm_write_bytes": wr, "mfma_util": util,
+                         "gui_cycles": gui, "wait_any": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
+                         "wait_inst": sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"]}
+            f.write(f"{name:20s} hbm_read={fe / 1e6:8.1f} MB hbm_write={wr / 1e6:8.1f} MB mfma_util={util:.3f} "
+                    f"gui_cycles={gui:.4g} wait_any={out[name]['wait_any']:.2f} wait_inst={out[name]['wait_inst']:.2f}  {f_[j][0][1][:70]}\n")
+    json.dump(out, open(f"{dst}/{R}_pmc_gemms{sfx}.json", "w"), indent=1)
+    print(open(f"{dst}/{R}_pmc_gemms{sfx}.txt").read())
+    return out
+
+
+pmc = {"f32": pmc_summary("", "fp32-MFMA engine"), "f32x3": pmc_summary("_x3", "split-fp32 engine")}
+for extra in ("layer_table_x3.txt", "bench_f32_mfma.json"):
+    if os.path.exists(f"{src}/{extra}"):
+        shutil.copy(f"{src}/{extra}", f"{dst}/{R}_{extra}")
+if os.path.exists(f"{src}/seq_x3.txt"):
+    with open(f"{dst}/{R}_seq_x3.txt", "w") as f:
+        f.write("VEEX_OVERLAP=0 rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 ... (split-fp32 engine, the default; "
+                "side stream off, so no kernel's duration is stretched by a concurrent one; tools/prof_seq.sh)\n")
+        f.write(open(f"{src}/seq_x3.txt").read())
 # bench.py ran before this run's counter passes were condensed, so its `traffic` came from the PREVIOUS summary in
 # profiles/: put this run's own figure in its place (same box, same build) and say so.
 bj = f"{dst}/{R}_bench.json"
-if os.path.exists(bj) and "dec.deconv4.fwd" in out:
+if os.path.exists(bj):
     lines = open(bj).read().strip().split("\n")
     d = json.loads(lines[-1])
-    if isinstance(d.get("roofline"), dict):
-        e = out["dec.deconv4.fwd"]
-        d["roofline"]["traffic"] = e["hbm_read_bytes"] + e["hbm_write_bytes"]
-        d["roofline"]["traffic_source"] = (d["roofline"].get("traffic_source") or "") + \
-            " [filled in by tools/summarize_profiles.py from the counter passes of the same run_profiles.sh call]"
-        lines[-1] = json.dumps(d)
-        open(bj, "w").write("\n".join(lines) + "\n")
+    eng = d.get("config", {}).get("engine", "f32")
+    for roof, out in ((d.get("roofline"), pmc.get(eng, {})), ((d.get("f32_mfma") or {}).get("roofline"), pmc["f32"])):
+        if isinstance(roof, dict) and "dec.deconv4.fwd" in out:
+            e = out["dec.deconv4.fwd"]
+            roof["traffic"] = e["hbm_read_bytes"] + e["hbm_write_bytes"]
+            roof["traffic_source"] = (roof.get("traffic_source") or "") + \
+                " [filled in by tools/summarize_profiles.py from the counter passes of the same run_profiles.sh call]"
+    lines[-1] = json.dumps(d)
+    open(bj, "w").write("\n".join(lines) + "\n")

@@ -501,7 +501,9 @@ static long long act_floats(const ConvLayer& c, int B) { return (long long)B * c
 static void wg_desc_deconv(const VeexNet* n, int i, int B, WGParams& p) {
   const ConvLayer& c = n->dc[i];
   memset(&p, 0, sizeof(p));
-  p.bf16 = (n->compute == VEEX_COMPUTE_BF16) ? 2 : 0;   // 2: both operands come as bf16 consumer copies
+  // 2: both operands come as bf16 consumer copies.  (The split-fp32 engine keeps its weight gradients on the fp32 MFMA:
+  // a split weight-gradient kernel measured 20-75 % slower than wgrad_gemm_v3.hip on every layer, profiles/r03_x3_wgrad.txt)
+  p.bf16 = (n->compute == VEEX_COMPUTE_BF16) ? 2 : 0;
   p.Nb = B; p.Hb = c.Hout; p.Wb = c.Hout; p.Cb = c.Cout; p.Hs = c.Hin; p.Ws = c.Hin; p.Cs = c.Cin;
   p.kh = c.k; p.kw = c.k; p.stride = c.stride; p.pb = c.pb;
   p.R = B * c.Hin * c.Hin; p.M = c.k * c.k * c.Cout;
@@ -885,17 +887,24 @@ static int join_side(Ctx& c) {
 // Weight gradient of one layer.  With a side stream the GEMM and its slab reduction run there,
 // concurrently with the input-gradient chain on the main stream (they only share read-only inputs;
 // measured -12..-14 % per dgrad+wgrad pair): fork after the producer of its operands, join at the end.
-static int run_wgrad(Ctx& c, WGParams& p, float* dW) {
+// layer: name for the timing probe ("<layer>.wgrad" arms the GEMM launch, on the stream it runs on)
+static int run_wgrad(Ctx& c, WGParams& p, float* dW, const char* layer = nullptr) {
   const SplitPlan s = wgrad_split(p);
   p.nsplit = s.nsplit; p.rows_per_split = s.per;
   const long long n = (long long)p.M * p.Cs;
   hipStream_t st = c.st;
   float* slab = c.ws + c.plan.slab;
   if (c.side != nullptr) { TRY(fork_side(c)); st = c.side; slab = c.ws + c.plan.slab_side; }
-  if (s.nsplit == 1) { p.Out = dW; return veex_launch_wgrad(p, st); }
-  if ((long long)s.nsplit * n > c.plan.slab_n) { veex_set_error("internal: slab scratch too small"); return VEEX_ENOMEM; }
-  p.Out = slab;
+  if (s.nsplit > 1 && (long long)s.nsplit * n > c.plan.slab_n) { veex_set_error("internal: slab scratch too small"); return VEEX_ENOMEM; }
+  p.Out = (s.nsplit == 1) ? dW : slab;
+  const bool probe = layer != nullptr && c.n->probe_state == 1 && c.n->probe_layer == std::string(layer) + ".wgrad";
+  if (probe && hipEventRecord(c.n->probe_ev[0], st) != hipSuccess) { veex_set_error("probe: event record failed"); return VEEX_ELAUNCH; }
   TRY(veex_launch_wgrad(p, st));
+  if (probe) {
+    if (hipEventRecord(c.n->probe_ev[1], st) != hipSuccess) { veex_set_error("probe: event record failed"); return VEEX_ELAUNCH; }
+    c.n->probe_state = 2;
+  }
+  if (s.nsplit == 1) return 0;
   return veex_slab_sum(slab, s.nsplit, n, n, dW, nullptr, 1, 0, st);
 }
 
@@ -1022,7 +1031,7 @@ static int encoder_backward(Ctx& c, const float* x, float* G, int want_param_gra
       w.BigBf = bfp(c, P.bf_act_conv[i - 1]); w.SmallBf = bfp(c, P.bf_d_conv[i]);
       w.b_scale = c.scale(n->conv[i - 1].bn); w.b_shift = c.shift(n->conv[i - 1].bn); w.b_aff_mask = n->conv[i - 1].Cout - 1;
       if (const float* y = bnp(c, P.bn_conv[i - 1])) { w.Big = y; w.b_scale = w.b_shift = nullptr; w.b_aff_mask = 0; }
-      TRY(run_wgrad(c, w, G + l.w));
+      TRY(run_wgrad(c, w, G + l.w, l.name));
     }
     GGParams p; memset(&p, 0, sizeof(p));
     p.A = ws + P.d_conv[i]; p.W = c.P + l.w; p.Wbf = packed_w(c, i - 1, 0);
@@ -1177,7 +1186,7 @@ extern "C" int veex_net_train_fwd_bwd(const VeexNet* n, const float* params, con
     const ConvLayer& prod = (i == 0) ? n->ddense : n->dc[i - 1];
     {
       WGParams w; deconv_wgrad_desc(c, i, w);
-      TRY(run_wgrad(c, w, G + l.w));
+      TRY(run_wgrad(c, w, G + l.w, l.name));
     }
     GGParams p; deconv_dgrad_desc(c, i, p);
     if (i > 0) {

@@ -82,7 +82,7 @@ struct WGParams {
   int rows_per_split;    // multiple of VEEX_BK
   int M;                 // kh*kw*Cb
   int nsplit;
-  int bf16;              // 1: bf16 MFMA (operands rounded while staging)
+  int bf16;              // 1: bf16 MFMA (operands rounded while staging); 2: + both operands as bf16 copies
   const void* BigBf;     // optional bf16 copies [rows][C] of Big / Small (BatchNorm already applied to the
   const void* SmallBf;   // activation side): staged with 16-byte copies + an in-register 8x8 transpose
   int gx, gy, gz;        // logical grid (m tiles, n tiles, row splits), filled by the launcher

@@ -81,8 +81,17 @@ def _transposed(W):
     return dst
 
 
-def gemm_cases(B, bf16=False):
-    """Yield (label, macs, launch_fn) for every MFMA launch of one train step at batch B."""
+def _pack3(W, transpose):
+    """three-term bf16 split [tap][Cin/16][plane][Cout][16] of a (k,k,rows,cols) kernel (veex_pack_weights_bf16x3)."""
+    k, _, rows, cols = W.shape
+    dst = torch.empty(3 * W.numel(), dtype=torch.bfloat16, device="cuda")
+    check(lib.veex_pack_weights_bf16x3(_lib.ptr(W), _lib.ptr(dst), k * k, rows, cols, transpose, _lib.current_stream()), "pack3")
+    return dst
+
+
+def gemm_cases(B, bf16=False, x3=False):
+    """Yield (label, macs, launch_fn) for every MFMA launch of one train step at batch B.  x3: the split-fp32 engine
+    (forward and input-gradient launches carry the three-plane weights; weight gradients are the fp32 engine's)."""
     stream = _lib.current_stream
     keep = []
     # fp32 engine: producers write a BatchNorm-applied fp32 copy (VeexGemmDesc::out_bn) and consumers read it without an
@@ -95,6 +104,9 @@ def gemm_cases(B, bf16=False):
         d.inp, d.weight, d.out = A.data_ptr(), W.data_ptr(), out.data_ptr()
         if wbf is None and mode == 0:
             wt = _transposed(W); keep.append(wt); d.weight_t = wt.data_ptr()
+        if x3:
+            w3 = _pack3(W, 1 if mode == 0 else 0); keep.append(w3)
+            d.weight_bf16, d.weight_planes = w3.data_ptr(), 3
         if wbf is not None:
             keep.append(wbf); d.weight_bf16 = wbf.data_ptr()
             # bf16 consumer copies as the network uses them: A with its BatchNorm applied, Out copy for the next layer
@@ -218,10 +230,15 @@ def algorithmic_bytes(label, B, bf16=False):
     return n_in * e + n_out * e + n_w * 4     # wgrad
 
 
-def layer_table(B=512, iters=10, bf16=False):
+PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0     # split-fp32: six bf16 MFMAs per fp32 multiply-accumulate
+
+
+def layer_table(B=512, iters=10, bf16=False, x3=False):
+    """x3: the split-fp32 engine; its forward / input-gradient launches are priced against the bf16 matrix pipe at six
+    MFMAs per product (416.7 TFLOP/s of fp32 work), its weight gradients against the fp32 MFMA peak they run on."""
     rows = []
-    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-    for label, macs, fn in gemm_cases(B, bf16):
+    for label, macs, fn in gemm_cases(B, bf16, x3):
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else (PEAK_X3_TFLOPS if (x3 and not label.endswith("wgrad")) else PEAK_F32_MFMA_TFLOPS)
         t = _time_launch(fn, iters)
         tf = 2.0 * macs / t / 1e12
         nbytes = algorithmic_bytes(label, B, bf16)
@@ -236,12 +253,12 @@ _PMC_NOTE = ("HBM bytes per launch (read + write) from separate rocprofv3 --pmc 
              "(tools/run_profiles.sh, batch 512; FETCH_SIZE doubled per the gfx950 correction), profiles/*_pmc_gemms.json")
 
 
-def _pmc_traffic(label, bf16=False):
+def _pmc_traffic(label, bf16=False, x3=False):
     """Per-launch HBM traffic of a GEMM from the newest committed PMC summary (counters cannot be
     collected inside bench.py: they need rocprofv3 passes of their own)."""
     import glob, json, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc_gemms_bf16.json" if bf16 else "r*_pmc_gemms.json")))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc_gemms_bf16.json" if bf16 else "r*_pmc_gemms_x3.json" if x3 else "r*_pmc_gemms.json")))
     if not files:
         return None
     try:
@@ -269,12 +286,16 @@ def _time_in_step(net, batch, layer, steps=20, warm=3):
 
 
 def dominant_kernel_roofline(net, batch):
-    """The MFMA launch with the largest share of the step (dec.deconv4 forward: the largest-FLOP
-    layer), timed live with HIP events on the launch stream."""
+    """The largest MFMA launch of the step (dec.deconv4 forward: the largest-FLOP layer), timed live with
+    HIP events on the launch stream inside real train steps.  Split-fp32 engine: the launch runs on the bf16 matrix
+    pipe at six MFMAs per fp32 multiply-accumulate, so its peak is 2500 / 6 = 416.7 TFLOP/s of fp32 work
+    (``frac`` = executed bf16 MFMA FLOP / 2.5 PFLOP/s); ``frac_of_f32_mfma_peak`` prices the same rate against the
+    157.3 TFLOP/s the fp32 MFMA instruction could reach at best."""
     best = None
-    bf16 = getattr(net, "compute", "f32") == "bf16"
-    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-    for label, macs, fn in gemm_cases(batch, bf16):
+    compute = getattr(net, "compute", "f32")
+    bf16, x3 = compute == "bf16", compute == "f32x3"
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_X3_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
+    for label, macs, fn in gemm_cases(batch, bf16, x3):
         if label != "dec.deconv4.fwd":
             continue
         t_alone = _time_launch(fn, iters=20, warm=3)
@@ -283,14 +304,18 @@ def dominant_kernel_roofline(net, batch):
         t = _time_in_step(net, batch, "dec.deconv4") or t_alone
         tf = 2.0 * macs / t / 1e12
         # the committed counter passes were taken at batch 512 (tools/run_profiles.sh)
-        traffic = _pmc_traffic("dec.deconv4.fwd", bf16) if batch == 512 else None
-        best = {"bound": "mfma", "kernel": ("gather_gemm_bf16_kernel" if bf16 else "gather_gemm_v3_kernel") +
-                " mode 1 (dec.deconv4 forward, Conv2DTranspose 128->64 k3 s1)",
+        traffic = _pmc_traffic("dec.deconv4.fwd", bf16, x3) if batch == 512 else None
+        kname = "gather_gemm_bf16_kernel" if bf16 else "gather_gemm_x3_kernel<256, 64, 32>" if x3 else "gather_gemm_v3_kernel"
+        best = {"bound": "mfma", "kernel": kname + " mode 1 (dec.deconv4 forward, Conv2DTranspose 128->64 k3 s1)",
                 "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                 "traffic": traffic, "traffic_source": _PMC_NOTE if traffic is not None else None, "us_per_launch": t * 1e6,
                 "us_per_launch_standalone": t_alone * 1e6, "algorithmic_flop_per_launch": 2.0 * macs,
                 "timing": "average over 20 train steps of HIP events recorded around this launch on its launch stream, inside "
                           "veex_net_train_fwd_bwd; us_per_launch_standalone = the same launch repeated back-to-back on its own"}
+        if x3:
+            best["peak_note"] = ("split-fp32 arithmetic: 6 v_mfma_f32_32x32x16_bf16 per 16 k of fp32 work -> 2500 / 6 TFLOP/s; "
+                                 "achieved / peak = executed bf16 MFMA FLOP / 2.5 PFLOP/s")
+            best["frac_of_f32_mfma_peak"] = tf / PEAK_F32_MFMA_TFLOPS
     return best
 
 
@@ -422,11 +447,12 @@ if __name__ == "__main__":
         sys.exit(0)
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     bf = len(sys.argv) > 2 and sys.argv[2] == "bf16"
+    x3 = len(sys.argv) > 2 and sys.argv[2] == "f32x3"
     tot = 0.0
-    print(f"MFMA launches of one train step at batch {B} ({'bf16' if bf else 'fp32'} engine), HIP-event time per launch; roof = "
-          f"max(FLOP / {'2500' if bf else '157.3'} TFLOP/s, algorithmic bytes / 8 TB/s)")
-    for r in layer_table(B, bf16=bf):
+    print(f"MFMA launches of one train step at batch {B} ({'bf16' if bf else 'split-fp32' if x3 else 'fp32'} engine), HIP-event time per launch; roof = "
+          f"max(FLOP / {'2500' if bf else '416.7 (forward, input gradient: 6 bf16 MFMAs per product) or 157.3 (weight gradient)' if x3 else '157.3'} TFLOP/s, algorithmic bytes / 8 TB/s)")
+    for r in layer_table(B, bf16=bf, x3=x3):
         tot += r["us"]
-        print(f"{r['kernel']:22s} {r['us']:8.1f} us  {r['tflops']:6.1f} TF  {100 * r['frac']:5.1f}% of {'bf16' if bf else 'f32'} MFMA peak"
+        print(f"{r['kernel']:22s} {r['us']:8.1f} us  {r['tflops']:6.1f} TF  {100 * r['frac']:5.1f}% of {'bf16' if bf else 'its' if x3 else 'f32'} MFMA peak"
               f"  bytes {r['bytes'] / 1e6:7.1f} MB  roof {r['roof_us']:6.1f} us ({r['roof']})  {100 * r['frac_roof']:5.1f}% of roof")
     print(f"sum {tot:.1f} us")
