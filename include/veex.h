@@ -99,7 +99,7 @@ typedef struct VeexGemmDesc {
   int32_t weight_planes;   /* 3: weight_bf16 holds the three-term bf16 split of the fp32 weights, [plane][tap][Cout][Cin]
                               (veex_pack_weights_bf16x3): the launch computes an fp32 result -- operands split into three
                               bf16 terms, six partial products per multiply, fp32 accumulate -- on the bf16 matrix cores
-                              (DESIGN.md 3.4).  0 / 1: weight_bf16 is the single rounded copy (bf16 engine). */
+                              (DESIGN.md 3.5).  0 / 1: weight_bf16 is the single rounded copy (bf16 engine). */
 } VeexGemmDesc;
 int veex_gather_gemm(const VeexGemmDesc* d, veexStream_t stream);
 /* bf16 copy of one layer's kernel for veex_gather_gemm: src fp32 [taps][rows][cols] ->
@@ -274,7 +274,7 @@ long long veex_net_ws_offset(const VeexNet* net, int batch, const char* name, lo
 #define VEEX_COMPUTE_F32 0
 #define VEEX_COMPUTE_BF16 1
 /* fp32 results on the bf16 matrix cores: every operand of the large conv / deconv GEMMs is split into three bf16 terms
- * and each product accumulated in fp32 from six partial products (DESIGN.md 3.4).  Same tolerance class as
+ * and each product accumulated in fp32 from six partial products (DESIGN.md 3.5).  Same tolerance class as
  * VEEX_COMPUTE_F32 (the parity tests run both at 1e-5); layers the split kernel does not win on stay on the fp32 MFMA. */
 #define VEEX_COMPUTE_F32X3 2
 int veex_net_set_compute(VeexNet* net, int compute);

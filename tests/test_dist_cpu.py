@@ -40,7 +40,14 @@ def _worker(rank, world, port, out_path):
     c = vo.forward(p, x[lo:hi], eps_mine, "vae")
     g = vo.backward(p, c, "vae")
     flat = torch.tensor(np.concatenate([_flat(g, names), [c["total"], c["rec_loss"], c["kl_loss"], 0.0]]))
+    # the two-bucket exchange (dist.TwoBucketReducer): one contiguous run reduced on its own, the pieces either side of
+    # it after it -- element for element the sums of the single all-reduce, bit for bit
+    pieces = flat.clone()
+    first, count = 1000, flat.numel() // 2
+    vdist.allreduce_sum_(pieces[first:first + count])
+    vdist.allreduce_sum_outside_(pieces, first, count)
     vdist.allreduce_sum_(flat)
+    assert torch.equal(pieces, flat)
     flat /= world                                   # the 1/world the Adam kernel folds into its gradient scale
     if rank == 0:
         cf = vo.forward(p, x, eps_full, "vae")

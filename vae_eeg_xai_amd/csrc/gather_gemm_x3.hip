@@ -302,34 +302,55 @@ __global__ __launch_bounds__(64 * WM * WN) void gather_gemm_x3_kernel(const GGPa
 // src fp32 [tap][R][C]: transpose != 0 -> n = column, k = row (N = C, K = R); else n = row, k = column.
 struct Pack3Job { const float* src; __bf16* dst; int taps, R, C, transpose, block0, blocks; };
 struct Pack3Jobs { int n; Pack3Job j[16]; };
+// One thread per (tap, 16-channel slice, n): 16 source values (a 64-byte run, or a stride-C column whose neighbours the
+// neighbouring threads read) -> one 32-byte row of each plane; consecutive threads write consecutive rows.
 __global__ __launch_bounds__(256) void pack_weights_bf16x3_multi_kernel(const Pack3Jobs jobs) {
   int k = 0;
   while (k + 1 < jobs.n && (int)blockIdx.x >= jobs.j[k + 1].block0) ++k;
   const Pack3Job J = jobs.j[k];
-  const long long n = (long long)J.taps * J.R * J.C, per = (long long)J.R * J.C;
-  const int N = J.transpose ? J.C : J.R, K = J.transpose ? J.R : J.C;
-  for (long long i = (long long)(blockIdx.x - J.block0) * 256 + threadIdx.x; i < n; i += (long long)J.blocks * 256) {
-    const long long t = i / per, rem = i - t * per;
-    const int r = (int)(rem / J.C), c = (int)(rem - (long long)r * J.C);       // coalesced reads of src
-    const int nn = J.transpose ? c : r, kk = J.transpose ? r : c;
-    __bf16 h1, h2, h3;
-    x3_split(J.src[i], h1, h2, h3);
-    const long long d0 = (((t * (K / 16) + kk / 16) * 3) * N + nn) * 16 + (kk & 15);
-    J.dst[d0] = h1; J.dst[d0 + (long long)N * 16] = h2; J.dst[d0 + 2LL * N * 16] = h3;
+  const int N = J.transpose ? J.C : J.R, K = J.transpose ? J.R : J.C, K16 = K / 16;
+  const long long per = (long long)J.R * J.C, items = (long long)J.taps * K16 * N;
+  for (long long i = (long long)(blockIdx.x - J.block0) * 256 + threadIdx.x; i < items; i += (long long)J.blocks * 256) {
+    const int nn = (int)(i % N);
+    const long long r = i / N;
+    const int k16 = (int)(r % K16), t = (int)(r / K16);
+    const float* src = J.src + t * per;
+    float v[16];
+    if (J.transpose) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = src[(long long)(k16 * 16 + j) * J.C + nn];
+    } else {
+      const float4* s4 = reinterpret_cast<const float4*>(src + (long long)nn * J.C + k16 * 16);   // C % 16 == 0
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float4 f = s4[j]; v[4 * j] = f.x; v[4 * j + 1] = f.y; v[4 * j + 2] = f.z; v[4 * j + 3] = f.w; }
+    }
+    bf16x8 h[3][2];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      __bf16 t1, t2, t3;
+      x3_split(v[j], t1, t2, t3);
+      h[0][j >> 3][j & 7] = t1; h[1][j >> 3][j & 7] = t2; h[2][j >> 3][j & 7] = t3;
+    }
+    __bf16* d = J.dst + (((long long)t * K16 + k16) * 3 * N + nn) * 16;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      *reinterpret_cast<bf16x8*>(d + (long long)pl * N * 16) = h[pl][0];
+      *reinterpret_cast<bf16x8*>(d + (long long)pl * N * 16 + 8) = h[pl][1];
+    }
   }
 }
 int veex_pack_weights_bf16x3_multi(int n, const float* const* src, void* const* dst, const int* taps, const int* rows,
                                    const int* cols, const int* transpose, hipStream_t st) {
   if (n < 1 || n > 16) { veex_set_error("pack_weights_bf16x3_multi: 1..16 jobs"); return -1; }
   for (int i = 0; i < n; ++i)
-    if ((transpose[i] ? rows[i] : cols[i]) % 16 != 0) { veex_set_error("pack_weights_bf16x3: the reduction dimension must be a multiple of 16"); return -1; }
+    if ((transpose[i] ? rows[i] : cols[i]) % 16 != 0 || cols[i] % 4 != 0) { veex_set_error("pack_weights_bf16x3: the reduction dimension must be a multiple of 16 (and the columns of 4)"); return -1; }
   Pack3Jobs jobs; jobs.n = n;
   int total = 0;
   for (int i = 0; i < n; ++i) {
-    const long long e = (long long)taps[i] * rows[i] * cols[i];
-    int b = (int)((e + 256 * 8 - 1) / (256 * 8));
+    const long long items = (long long)taps[i] * rows[i] * cols[i] / 16;   // one thread each
+    int b = (int)((items + 255) / 256);
     if (b < 1) b = 1;
-    if (b > 256) b = 256;
+    if (b > 512) b = 512;
     jobs.j[i].src = src[i]; jobs.j[i].dst = reinterpret_cast<__bf16*>(dst[i]);
     jobs.j[i].taps = taps[i]; jobs.j[i].R = rows[i]; jobs.j[i].C = cols[i]; jobs.j[i].transpose = transpose[i];
     jobs.j[i].block0 = total; jobs.j[i].blocks = b;
@@ -412,8 +433,11 @@ int veex_gg_x3_cfg(const GGParams& p) {
   if (cfg == -1) return -1;
   // the table's tile (or the largest) only while it still gives every CU a workgroup; else smaller tiles
   auto blocks = [&](int c) { return ((M + x3_bm_of(c) - 1) / x3_bm_of(c)) * ((p.Cout + x3_bn_of(c) - 1) / x3_bn_of(c)); };
+  // (a table entry was measured with the grid it has at batch 512 -- enc.conv3 forward runs 200 workgroups of 128 x 128
+  //  faster than 800 of 64 x 64 -- and is kept down to half of that; the size rule wants every CU to have a workgroup)
+  const long long floor_blocks = (cfg == -2) ? 256 : 96;
   if (cfg == -2) cfg = (p.Cout > 64) ? 2 : 4;
-  if (force < 0 && blocks(cfg) < 256) cfg = (p.Cout > 64 && blocks(5) >= 256) ? 5 : 0;
+  if (force < 0 && blocks(cfg) < floor_blocks) cfg = (p.Cout > 64 && blocks(5) >= 256) ? 5 : 0;
   return cfg;
 }
 

@@ -687,6 +687,9 @@ static int check_common(const VeexNet* n, const void* params, const void* state,
 // fp32 engine: transposed copies for the mode-0 launches of the lean kernel (the Conv2D forwards; with `bwd` also the
 // Conv2DTranspose input gradients), one launch per call -- the weights change every step
 static int run_transpose_weights(Ctx& c, bool enc, bool bwd) {
+  // split-fp32 engine from batch 256 up: every mode-0 launch of the big layers runs on the split kernel (N*Hout*Wout >= 4096
+  // for all of them), which reads its own packed planes -- nobody would read the transposed fp32 copies
+  if (c.n->compute == VEEX_COMPUTE_F32X3 && c.B >= 256) { c.have_wt_enc = c.have_wt_bwd = false; return 0; }
   const float* src[7]; float* dst[7]; int taps[7], rows[7], cols[7];
   int k = 0;
   for (int i = 0; i < 7; ++i) {

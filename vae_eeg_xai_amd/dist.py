@@ -69,13 +69,23 @@ class TwoBucketReducer:
             self.comm.wait_stream(cur)              # (an empty shard: the buffer was zeroed on the current stream)
         with torch.cuda.stream(self.comm):
             _all_reduce_(early, dist.ReduceOp.SUM)
-        _all_reduce_(g[:self.first], dist.ReduceOp.SUM)
-        _all_reduce_(g[self.first + self.count:], dist.ReduceOp.SUM)
+        allreduce_sum_outside_(g, self.first, self.count)
         cur.wait_stream(self.comm)
         return g
 
     def close(self):
         self.net.set_bucket_event(None)
+
+
+def allreduce_sum_outside_(g: torch.Tensor, first: int, count: int) -> torch.Tensor:
+    """SUM all-reduce of everything in the flat buffer EXCEPT ``g[first:first+count]`` (the late pieces of the
+    two-bucket exchange: the tensors before the decoder's run, and the BatchNorm parameters + loss scalars after it)."""
+    if world_size() > 1:
+        if first > 0:
+            _all_reduce_(g[:first], dist.ReduceOp.SUM)
+        if first + count < g.numel():
+            _all_reduce_(g[first + count:], dist.ReduceOp.SUM)
+    return g
 
 
 def allreduce_max_(t: torch.Tensor) -> torch.Tensor:
