@@ -1,5 +1,6 @@
 """Split-fp32 (three bf16 terms, six partial products) gather kernel against the fp32-MFMA kernel: per launch time and
-the difference of the results.  usage: python tools/x3_try.py [batch]"""
+the difference of the results, per tile configuration (VEEX_X3_CFG: a `make TIMING=1` build; the shipped library runs its
+table whatever the variable says).  usage: python tools/x3_try.py [batch]"""
 import ctypes as C
 import os
 import sys
@@ -48,16 +49,16 @@ def main():
         out2 = torch.full(shape, 7.0, device="cuda"); d2.out = out2.data_ptr()
         f2 = lambda: check(lib.veex_gather_gemm(C.byref(d2), _lib.current_stream()), label)
         res = []
-        for cfg, nst in [(int(c), n) for c in os.environ.get('X3_CFGS', '2,3,5').split(',') for n in (2, 3, 4)]:
-            _lib.setenv("VEEX_X3_CFG", cfg); _lib.setenv("VEEX_X3_NST", nst)
+        for cfg, nst in [(int(c), 2) for c in os.environ.get('X3_CFGS', '-2,0,2,3,4,5,6').split(',')]:   # -2 = the shipped table
+            _lib.setenv("VEEX_X3_CFG", cfg)
             if d.epilogue == 1:
                 mt = lib.veex_gather_gemm_m_tiles(C.byref(d2))
             out2.fill_(7.0)
             t3 = timed(f2)
             torch.cuda.synchronize()
             diff = (out2 - ref).abs().max().item() / ref.abs().max().item()
-            res.append((t3, f"{cfg}/{nst}", diff))
-        _lib.setenv("VEEX_X3_CFG", None); _lib.setenv("VEEX_X3_NST", None)
+            res.append((t3, f"cfg{cfg}", diff))
+        _lib.setenv("VEEX_X3_CFG", None)
         t3 = min(res)[0]
         tot32 += t32; tot3 += t3
         print(f"{label:20s} fp32 {t32:7.1f} us | " + " | ".join(f"{c} {t:6.1f}" + ("" if df < 5e-6 else f" BAD {df:.1e}") for t, c, df in res), flush=True)

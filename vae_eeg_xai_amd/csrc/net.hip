@@ -502,7 +502,8 @@ static void wg_desc_deconv(const VeexNet* n, int i, int B, WGParams& p) {
   const ConvLayer& c = n->dc[i];
   memset(&p, 0, sizeof(p));
   // 2: both operands come as bf16 consumer copies.  (The split-fp32 engine keeps its weight gradients on the fp32 MFMA:
-  // a split weight-gradient kernel measured 20-75 % slower than wgrad_gemm_v3.hip on every layer, profiles/r03_x3_wgrad.txt)
+  // two split weight-gradient kernels were measured: 20-75 % slower than wgrad_gemm_v3.hip, then on a par with it but
+  // unable to share a CU with the split gather kernel, profiles/r03_x3_wgrad.txt, r03_x3_specialised.txt)
   p.bf16 = (n->compute == VEEX_COMPUTE_BF16) ? 2 : 0;
   p.Nb = B; p.Hb = c.Hout; p.Wb = c.Hout; p.Cb = c.Cout; p.Hs = c.Hin; p.Ws = c.Hin; p.Cs = c.Cin;
   p.kh = c.k; p.kw = c.k; p.stride = c.stride; p.pb = c.pb;
