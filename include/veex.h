@@ -36,7 +36,9 @@ typedef struct ihipStream_t* veexStream_t; /* == hipStream_t */
 
 /* Version of the descriptor structs and entry points declared here; veex_abi_version() returns the version the
  * LIBRARY was built with.  A caller compiled against an older header must refuse to run when the two differ:
- * VeexGemmDesc grew (weight_t, out_bn) in version 2 and the library reads those fields. */
+ * VeexGemmDesc grew (weight_t, out_bn) in version 2 and the library reads those fields.  From version 3 on the structs
+ * carry struct_size, so growth at the end (weight_planes, round 3) does not change the version: fields at or beyond the
+ * caller's struct_size are not read. */
 #define VEEX_ABI_VERSION 3
 const char* veex_last_error(void);
 int veex_abi_version(void);

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_descriptor_structs_match_header():
     from vae_eeg_xai_amd._lib import GemmDesc, WgradDesc
-    assert C.sizeof(GemmDesc) == 9 * 8 + 18 * 4 + 4 * 8 + 2 * 4 + 8 + 8 + 8
+    assert C.sizeof(GemmDesc) == 9 * 8 + 18 * 4 + 4 * 8 + 2 * 4 + 8 + 8 + 8 + 8      # (+ weight_planes and its padding)
     assert C.sizeof(WgradDesc) == 7 * 8 + 18 * 4 + 2 * 8
 
 

@@ -126,6 +126,8 @@ class Net:
         on = bool(on) and os.environ.get("VEEX_OVERLAP", "1") != "0"
         if on and self._side_stream is None:
             with torch.cuda.device(self.device):
+                # (normal priority on purpose: a LOWER-priority side stream measured -1.4 .. -2.0 % on the step, and then hung
+                #  a test in which a stream of normal priority waited on it -- DESIGN.md 7)
                 self._side_stream = torch.cuda.Stream(device=self.device, priority=0)
         s = self._side_stream.cuda_stream if on else None
         check(lib.veex_net_set_side_stream(self._h, C.c_void_p(s) if s is not None else None), "net_set_side_stream")
