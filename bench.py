@@ -344,8 +344,9 @@ def main():
             "config": {"workload": (f"configs[1]: models.py VAE train_step, 100k synthetic 40x40 topomaps, batch {B}/GPU, "
                                     if world == 1 else
                                     f"configs[2]: data-parallel models.py VAE train_step, global batch {B * world} "
-                                    f"({B}/GPU x {world} GPUs; 8192 on 8), one RCCL all-reduce of the flat gradient "
-                                    f"buffer per step, {n_local} synthetic 40x40 topomaps resident per GPU, ") +
+                                    f"({B}/GPU x {world} GPUs; 8192 on 8), the flat gradient buffer all-reduced over RCCL once per "
+                                    f"step ({'two buckets: the decoder share on a communication stream under the encoder backward' if args.buckets == 2 else 'one collective'}), "
+                                    f"{n_local} synthetic 40x40 topomaps resident per GPU, ") +
                                    f"latent {L}, Adam lr 1e-5, " +
                                    {"f32": "fp32 (fp32 MFMA instructions)",
                                     "f32x3": "fp32 results, split-fp32 engine: the conv / deconv forward and input-gradient GEMMs "

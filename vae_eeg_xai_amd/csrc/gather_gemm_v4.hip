@@ -251,7 +251,9 @@ __global__ __launch_bounds__(256) void gather_gemm_v4_kernel(const GGParams p) {
 // callers size the column partials by it)
 int veex_gg_v4_ok(const GGParams& p) {
   if (!veex_env_int("VEEX_GGV4", 1)) return 0;
-  if (p.Wbf != nullptr || p.Abf != nullptr || p.OutBf != nullptr || p.a_scale != nullptr) return 0;
+  // (wplanes == 3: the split-fp32 engine's weight planes ride along on every descriptor; a launch its kernel does not
+  //  take is an fp32 launch like any other)
+  if ((p.Wbf != nullptr && p.wplanes != 3) || p.Abf != nullptr || p.OutBf != nullptr || p.a_scale != nullptr) return 0;
   if (p.epi == VEEX_EPI_RAW || p.nsplit > 1 || p.Out == nullptr) return 0;
   if (p.mode == 0 && p.Wt == nullptr) return 0;
   if (p.mode == 1 && p.stride != 1 && p.stride != 2) return 0;
