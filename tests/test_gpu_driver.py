@@ -129,3 +129,19 @@ def test_fit_from_a_captured_graph_equals_the_eager_fit(variant):
     (a1, a2, pa, va, sa), (b1, b2, pb, vb, sb) = out
     assert a1 == b1 and a2 == b2 and sa == sb
     assert torch.equal(pa, pb) and torch.equal(va, vb)
+
+
+def test_fit_on_the_split_fp32_engine_equals_the_fp32_mfma_fit():
+    """VAE(..., compute="f32x3"): the same fit on the two fp32 engines (batch 128: the split kernel takes launches) --
+    every logged metric within 1e-5 of the other engine's."""
+    from vae_eeg_xai_amd.models import Encoder, Decoder, VAE, Adam
+    x = vo.synth_topomaps(384 + 128, 21)
+    hist = {}
+    for compute in ("f32", "f32x3"):
+        model = VAE(Encoder(28), Decoder(), compute=compute)
+        assert model._net.compute == compute
+        model.compile(Adam(1e-5))
+        hist[compute] = model.fit(x[:384], x[:384], 128, 2, validation_data=(x[384:], x[384:]), verbose=0, seed=5).history
+    for k, v in hist["f32"].items():
+        for a, b in zip(v, hist["f32x3"][k]):
+            assert abs(a - b) <= 1e-5 * max(abs(a), 1.0), (k, a, b)
