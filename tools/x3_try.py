@@ -49,16 +49,19 @@ def main():
         out2 = torch.full(shape, 7.0, device="cuda"); d2.out = out2.data_ptr()
         f2 = lambda: check(lib.veex_gather_gemm(C.byref(d2), _lib.current_stream()), label)
         res = []
-        for cfg, nst in [(int(c), 2) for c in os.environ.get('X3_CFGS', '-2,0,2,3,4,5,6').split(',')]:   # -2 = the shipped table
+        opts = [int(o) for o in os.environ.get('X3_OPTS', '0').split(',')]      # VEEX_X3_OPT: 1 swizzled rows, 2 store first
+        for cfg, opt in [(int(c), o) for c in os.environ.get('X3_CFGS', '-2,0,2,3,4,5,6').split(',') for o in opts]:   # -2 = the shipped table
             _lib.setenv("VEEX_X3_CFG", cfg)
+            _lib.setenv("VEEX_X3_OPT", opt if opt else None)
             if d.epilogue == 1:
                 mt = lib.veex_gather_gemm_m_tiles(C.byref(d2))
             out2.fill_(7.0)
             t3 = timed(f2)
             torch.cuda.synchronize()
             diff = (out2 - ref).abs().max().item() / ref.abs().max().item()
-            res.append((t3, f"cfg{cfg}", diff))
+            res.append((t3, f"cfg{cfg}" + (f"/opt{opt}" if len(opts) > 1 else ""), diff))
         _lib.setenv("VEEX_X3_CFG", None)
+        _lib.setenv("VEEX_X3_OPT", None)
         t3 = min(res)[0]
         tot32 += t32; tot3 += t3
         print(f"{label:20s} fp32 {t32:7.1f} us | " + " | ".join(f"{c} {t:6.1f}" + ("" if df < 5e-6 else f" BAD {df:.1e}") for t, c, df in res), flush=True)

@@ -12,7 +12,8 @@
 // split while a tile is staged into LDS (after the BN affine); the weights come pre-split as three packed bf16 planes
 // [tap][Cin/16][plane][Cout][16] (veex_pack_weights_bf16x3, once per step from the fp32 master weights: a K chunk's
 // weight tile is one contiguous run per plane).
-// Tiles from 64 x 64 x 32 (4 waves) to 256 x 128 x 16 (8 waves, 110 KB of LDS: 3 planes x 2 buffers), chosen per layer.
+// Tiles from 64 x 64 x 32 (4 waves) to 256 x 128 x 16 (8 waves, 74 KB of LDS: 3 planes x 2 buffers), chosen per layer;
+// LDS rows are unpadded with their 16-byte pieces XOR-swizzled by the row (no bank conflict on either side).
 #include "gg_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -38,10 +39,18 @@ __device__ __forceinline__ void x3_split(float v, __bf16& h1, __bf16& h2, __bf16
   h3 = (__bf16)r2;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool MODE1, int AFF, int NST>
+// DBG (a `make TIMING=1` build only; results are WRONG by construction): 1 no global loads, 2 no split arithmetic (one
+// conversion per element), 4 no LDS stores, 8 no MFMAs (the operand reads stay), 16 no operand reads (the MFMAs stay).
+// OPT bit 0: unpadded LDS rows with the 16-byte pieces of a row XOR-swizzled by the row (conflict-free ds_read_b128 AND
+// ds_write_b128; the padded rows' stores are 2-way); bit 1: a step converts and stores the next chunk BEFORE its MFMAs in
+// program order (its loads were issued a whole step earlier), so the scheduler may spread the stores under the MFMAs.
+template <int BM, int BN, int BK, int WM, int WN, bool MODE1, int AFF, int NST, int OPT = 0, int DBG = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gather_gemm_x3_kernel(const GGParams p) {
   constexpr int NTHR = 64 * WM * WN;
-  constexpr int LDKH = BK + 8;         // bf16 elements per LDS row (80 / 48 B: conflict-free b128 reads)
+  constexpr bool SWZ = (OPT & 1) != 0, STORE_FIRST = (OPT & 2) != 0;
+  constexpr int LDKH = SWZ ? BK : BK + 8;   // bf16 elements per LDS row (padded: 80 / 48 B, conflict-free b128 reads)
+  // swizzle of a row's 16-byte pieces: 64-byte rows (BK 32) by (row >> 2) & 3, 32-byte rows (BK 16) by (row >> 3) & 1
+  auto swz = [](int row) { return SWZ ? (BK == 32 ? (row >> 2) & 3 : (row >> 3) & 1) : 0; };
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MT = WTM / 32, NT = WTN / 32;
   constexpr int AQ = BK / 8;           // A: 32-byte pieces (8 fp32 channels = two 16-byte loads) per row
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gather_gemm_x3_kernel(const GGPa
     const int t = vr / BN, row = vr - t * BN, h = t / 3, pl = t - 3 * h;
     b_ok[i] = pi < BPIECES && n0 + row < p.Cout;
     b_goff[i] = ((h * 3 + pl) * p.Cout + n0 + row) * 32 + bq * 16;
-    b_lds[i] = pl * B_ELEMS + row * LDKH + h * 16 + bq * 8;
+    b_lds[i] = pl * B_ELEMS + row * LDKH + ((h * 2 + bq) ^ swz(row)) * 8;
   }
   const int c16_bytes = 3 * p.Cout * 32;          // one 16-channel slice of one tap, three planes
   const int tap_c16 = p.Cin / 16;
@@ -182,8 +191,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gather_gemm_x3_kernel(const GGPa
     for (int i = 0; i < APASS; ++i) {
       const bool ok = cvalid && ((a_mask[i] >> tapi) & 1u);
       const unsigned aoff = ok ? (unsigned)(a_rowbase[i] + delta) : VEEX_OOB;
-      st.ra[i][0] = bload4(rA, aoff);
-      st.ra[i][1] = bload4(rA, aoff + 16u);
+      if (DBG & 1) {
+        asm volatile("" : "=v"(st.ra[i][0].x), "=v"(st.ra[i][0].y), "=v"(st.ra[i][0].z), "=v"(st.ra[i][0].w) : "v"(aoff));
+        asm volatile("" : "=v"(st.ra[i][1].x), "=v"(st.ra[i][1].y), "=v"(st.ra[i][1].z), "=v"(st.ra[i][1].w) : "v"(aoff));
+      } else {
+        st.ra[i][0] = bload4(rA, aoff);
+        st.ra[i][1] = bload4(rA, aoff + 16u);
+      }
       st.rok[i] = ok;
       if (AFF == 2) {
         const unsigned ao = ok ? (unsigned)(a_rowbase[i] + delta - a_nbase[i]) : VEEX_OOB;
@@ -200,7 +214,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gather_gemm_x3_kernel(const GGPa
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
       const bool ok = cvalid && b_ok[i];
-      st.rb[i] = x3_bload4u(rW, ok ? (unsigned)(wbase + b_goff[i]) : VEEX_OOB);
+      const unsigned boff = ok ? (unsigned)(wbase + b_goff[i]) : VEEX_OOB;
+      if (DBG & 1) asm volatile("" : "=v"(st.rb[i].x), "=v"(st.rb[i].y), "=v"(st.rb[i].z), "=v"(st.rb[i].w) : "v"(boff));
+      else st.rb[i] = x3_bload4u(rW, boff);
     }
   };
 
@@ -222,18 +238,26 @@ __global__ __launch_bounds__(64 * WM * WN) void gather_gemm_x3_kernel(const GGPa
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           __bf16 t1, t2, t3;
-          x3_split(vv[e], t1, t2, t3);
+          if (DBG & 2) { t1 = (__bf16)vv[e]; t2 = t1; t3 = t1; }
+          else x3_split(vv[e], t1, t2, t3);
           h1[4 * hq + e] = t1; h2[4 * hq + e] = t2; h3[4 * hq + e] = t3;
         }
       }
-      __bf16* d = as + (lr + ARP * i) * LDKH + 8 * q;
-      *reinterpret_cast<bf16x8*>(d) = h1;
-      *reinterpret_cast<bf16x8*>(d + A_ELEMS) = h2;
-      *reinterpret_cast<bf16x8*>(d + 2 * A_ELEMS) = h3;
+      __bf16* d = as + (lr + ARP * i) * LDKH + 8 * (q ^ swz(lr + ARP * i));
+      if (DBG & 4) {
+        asm volatile("" : : "v"(h1), "v"(h2), "v"(h3), "v"(d));
+      } else {
+        *reinterpret_cast<bf16x8*>(d) = h1;
+        *reinterpret_cast<bf16x8*>(d + A_ELEMS) = h2;
+        *reinterpret_cast<bf16x8*>(d + 2 * A_ELEMS) = h3;
+      }
     }
 #pragma unroll
     for (int i = 0; i < BPASS; ++i)
-      if (BPIECES % NTHR == 0 || tid + NTHR * i < BPIECES) *reinterpret_cast<uint4*>(bs + b_lds[i]) = st.rb[i];
+      if (BPIECES % NTHR == 0 || tid + NTHR * i < BPIECES) {
+        if (DBG & 4) asm volatile("" : : "v"(st.rb[i].x), "v"(st.rb[i].y), "v"(st.rb[i].z), "v"(st.rb[i].w), "v"(bs + b_lds[i]));
+        else *reinterpret_cast<uint4*>(bs + b_lds[i]) = st.rb[i];
+      }
   };
 
   f32x16 acc[MT][NT];
@@ -245,17 +269,35 @@ __global__ __launch_bounds__(64 * WM * WN) void gather_gemm_x3_kernel(const GGPa
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   auto compute = [&](int cur) {
-    const __bf16* as = As + cur * 3 * A_ELEMS + (wm * WTM + l31) * LDKH + 8 * lh;
-    const __bf16* bs = Bs + cur * 3 * B_ELEMS + (wn * WTN + l31) * LDKH + 8 * lh;
+    // (tile origins are multiples of 32 rows: the swizzle of a lane's row depends on l31 alone)
+    const __bf16* as = As + cur * 3 * A_ELEMS + (wm * WTM + l31) * LDKH;
+    const __bf16* bs = Bs + cur * 3 * B_ELEMS + (wn * WTN + l31) * LDKH;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
+      const int ko = 8 * ((2 * ks + lh) ^ swz(l31));
       bf16x8 av[3][MT], bv[3][NT];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) av[pl][i] = *reinterpret_cast<const bf16x8*>(as + pl * A_ELEMS + i * 32 * LDKH + 16 * ks);
+        for (int i = 0; i < MT; ++i) {
+          if (DBG & 16) asm volatile("" : "=v"(av[pl][i]) : "v"(as + pl * A_ELEMS + i * 32 * LDKH + ko));
+          else av[pl][i] = *reinterpret_cast<const bf16x8*>(as + pl * A_ELEMS + i * 32 * LDKH + ko);
+        }
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bv[pl][j] = *reinterpret_cast<const bf16x8*>(bs + pl * B_ELEMS + j * 32 * LDKH + 16 * ks);
+        for (int j = 0; j < NT; ++j) {
+          if (DBG & 16) asm volatile("" : "=v"(bv[pl][j]) : "v"(bs + pl * B_ELEMS + j * 32 * LDKH + ko));
+          else bv[pl][j] = *reinterpret_cast<const bf16x8*>(bs + pl * B_ELEMS + j * 32 * LDKH + ko);
+        }
+      }
+      if (DBG & 8) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i) asm volatile("" : : "v"(av[pl][i]));
+#pragma unroll
+          for (int j = 0; j < NT; ++j) asm volatile("" : : "v"(bv[pl][j]));
+        }
+        continue;
       }
       // smallest terms first; consecutive MFMAs go to different accumulators
 #pragma unroll
@@ -278,15 +320,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gather_gemm_x3_kernel(const GGPa
   store_chunk(st[0], 0);
 #pragma unroll
   for (int k = 1; k < NST; ++k) load_chunk(st[k], c_begin + k < c_end);
+  if (STORE_FIRST) load_chunk(st[0], c_begin + NST < c_end);   // (stage j % NST holds chunk j; a step refills the stage it stored)
   __syncthreads();
   constexpr int U = (NST % 2 == 0) ? NST : 2 * NST;
   for (int c = c_begin; c < c_end; c += U) {
 #pragma unroll
     for (int k = 0; k < U; ++k) {
       if (c + k < c_end) {            // (wave-uniform)
-        load_chunk(st[k % NST], c + k + NST < c_end);
-        compute(k & 1);
-        store_chunk(st[(k + 1) % NST], (k + 1) & 1);
+        if (STORE_FIRST) {
+          store_chunk(st[(k + 1) % NST], (k + 1) & 1);
+          load_chunk(st[(k + 1) % NST], c + k + 1 + NST < c_end);
+          compute(k & 1);
+        } else {
+          load_chunk(st[k % NST], c + k + NST < c_end);
+          compute(k & 1);
+          store_chunk(st[(k + 1) % NST], (k + 1) & 1);
+        }
         __syncthreads();
       }
     }
@@ -368,27 +417,40 @@ extern "C" int veex_pack_weights_bf16x3(const float* src, void* dst, int taps, i
 // ---------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int BK>
-static constexpr size_t x3_lds_bytes() { return (size_t)(2 * 3 * (BM + BN) * (BK + 8)) * 2 + BM * sizeof(int); }
+template <int BM, int BN, int BK, int OPT>
+static constexpr size_t x3_lds_bytes() { return (size_t)(2 * 3 * (BM + BN) * (BK + ((OPT & 1) ? 0 : 8))) * 2 + BM * sizeof(int); }
 
-template <int BM, int BN, int BK, int WM, int WN, bool MODE1, int NST>
+template <int BM, int BN, int BK, int WM, int WN, bool MODE1, int NST, int OPT>
 static int x3_launch_n(const GGParams& p, dim3 grid, hipStream_t st) {
-  constexpr size_t lds = x3_lds_bytes<BM, BN, BK>();
-  static_assert(lds <= 160 * 1024, "LDS of one CU");
+  constexpr size_t lds = x3_lds_bytes<BM, BN, BK, OPT>();
+  static_assert(x3_lds_bytes<BM, BN, BK, OPT>() <= 160 * 1024, "LDS of one CU");
   const int aff = (p.a_scale == nullptr) ? 0 : (p.aff_spatial ? 2 : 1);
   static bool attr_done = false;   // function attributes are per process; set them once, outside any capture
   if (!attr_done && lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gather_gemm_x3_kernel<BM, BN, BK, WM, WN, MODE1, 0, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gather_gemm_x3_kernel<BM, BN, BK, WM, WN, MODE1, 1, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gather_gemm_x3_kernel<BM, BN, BK, WM, WN, MODE1, 2, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gather_gemm_x3_kernel<BM, BN, BK, WM, WN, MODE1, 0, NST, OPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gather_gemm_x3_kernel<BM, BN, BK, WM, WN, MODE1, 1, NST, OPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gather_gemm_x3_kernel<BM, BN, BK, WM, WN, MODE1, 2, NST, OPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       veex_set_error("gather_gemm(x3): cannot raise the dynamic LDS limit"); return -3;
     }
   }
   attr_done = true;
   const dim3 blk(64 * WM * WN);
-  if (aff == 0) hipLaunchKernelGGL((gather_gemm_x3_kernel<BM, BN, BK, WM, WN, MODE1, 0, NST>), grid, blk, lds, st, p);
-  else if (aff == 1) hipLaunchKernelGGL((gather_gemm_x3_kernel<BM, BN, BK, WM, WN, MODE1, 1, NST>), grid, blk, lds, st, p);
-  else hipLaunchKernelGGL((gather_gemm_x3_kernel<BM, BN, BK, WM, WN, MODE1, 2, NST>), grid, blk, lds, st, p);
+#ifdef VEEX_DEBUG_TIMING
+  if constexpr (OPT == 1) if (const int dbg = veex_tune_int("VEEX_X3_DBG", 0)) {      // ablations (AFF-less instantiation whatever the launch asks)
+    static bool dbg_attr = false;
+#define X3_DBG_CASE(D) case D: { auto kfn = gather_gemm_x3_kernel<BM, BN, BK, WM, WN, MODE1, 0, NST, OPT, D>; \
+      if (!dbg_attr && lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipLaunchKernelGGL(kfn, grid, blk, lds, st, p); break; }
+    switch (dbg) { X3_DBG_CASE(1) X3_DBG_CASE(2) X3_DBG_CASE(4) X3_DBG_CASE(8) X3_DBG_CASE(16) X3_DBG_CASE(3) X3_DBG_CASE(7) X3_DBG_CASE(24)
+      default: veex_set_error("VEEX_X3_DBG: 1, 2, 3, 4, 7, 8, 16 or 24"); return -1; }
+#undef X3_DBG_CASE
+    VEEX_CHECK_LAUNCH();
+    return 0;
+  }
+#endif
+  if (aff == 0) hipLaunchKernelGGL((gather_gemm_x3_kernel<BM, BN, BK, WM, WN, MODE1, 0, NST, OPT>), grid, blk, lds, st, p);
+  else if (aff == 1) hipLaunchKernelGGL((gather_gemm_x3_kernel<BM, BN, BK, WM, WN, MODE1, 1, NST, OPT>), grid, blk, lds, st, p);
+  else hipLaunchKernelGGL((gather_gemm_x3_kernel<BM, BN, BK, WM, WN, MODE1, 2, NST, OPT>), grid, blk, lds, st, p);
   VEEX_CHECK_LAUNCH();
   return 0;
 }
@@ -396,32 +458,44 @@ static int x3_launch_n(const GGParams& p, dim3 grid, hipStream_t st) {
 template <int BM, int BN, int BK, int WM, int WN, bool MODE1>
 static int x3_launch(const GGParams& p, dim3 grid, hipStream_t st) {
   // register stages: 2, 3 and 4 chunks of loads in flight measure the same on every layer (profiles/r03_x3_sweep.txt)
-  return x3_launch_n<BM, BN, BK, WM, WN, MODE1, 2>(p, grid, st);
+#ifdef VEEX_DEBUG_TIMING
+  switch (veex_tune_int("VEEX_X3_OPT", 1)) {      // (A/B of the kernel's OPT bits)
+    case 0: return x3_launch_n<BM, BN, BK, WM, WN, MODE1, 2, 0>(p, grid, st);
+    case 2: return x3_launch_n<BM, BN, BK, WM, WN, MODE1, 2, 2>(p, grid, st);
+    case 3: return x3_launch_n<BM, BN, BK, WM, WN, MODE1, 2, 3>(p, grid, st);
+    default: break;
+  }
+#endif
+  // swizzled rows: 1-3 % on most layers and an extra workgroup per CU for the 16-deep tiles; converting and storing the
+  // next chunk before the step's MFMAs (bit 1) measured 2-8 % slower (profiles/r03_x3_sweep_swizzled.txt)
+  return x3_launch_n<BM, BN, BK, WM, WN, MODE1, 2, 1>(p, grid, st);
 }
 
-// Tile configuration: 0 = 64 x 64 x 32 (4 waves, two workgroups per CU), 2 = 128 x 128 x 32 (8 waves), 3 = 256 x 128 x 16
-// (8 waves), 4 = 256 x 64 x 32 (8 waves), 5 = 128 x 128 x 16 (4 waves, two workgroups per CU), 6 = 128 x 64 x 16 (4 waves);
-// -1 = the launch stays on the fp32-MFMA kernel.  Measured per layer at batch 512 (tools/x3_try.py,
-// profiles/r03_x3_sweep.txt); geometries outside the table take the size rule below.
+// Tile configuration: 0 = 64 x 64 x 32 (4 waves), 2 = 128 x 128 x 32 (8 waves, one workgroup per CU), 3 = 256 x 128 x 16
+// (8 waves), 4 = 256 x 64 x 32 (8 waves), 5 = 128 x 128 x 16 (4 waves, three workgroups per CU), 6 = 128 x 64 x 16 (4 waves,
+// four per CU), 7 = 128 x 64 x 32 (4 waves, two per CU), 8 = 256 x 64 x 16 (8 waves, two per CU); -1 = the launch stays on
+// the fp32-MFMA kernel.  Measured per layer at batch 512 with the swizzled LDS rows (tools/x3_try.py,
+// profiles/r03_x3_sweep_swizzled.txt; the padded-row sweep is profiles/r03_x3_sweep.txt); geometries outside the table
+// take the size rule below.
 struct X3Known { int mode, stride, Hin, Cin, Cout, cfg; };
 static const X3Known X3_KNOWN[] = {
-    {0, 2, 20, 64, 128, 5},    // enc.conv2 forward            52 us (fp32 MFMA kernel: 82)
-    {1, 2, 10, 128, 64, -1},   // enc.conv2 input gradient     69 = 68
-    {0, 2, 10, 128, 256, 2},   // enc.conv3 forward            49 (69)
-    {1, 2, 5, 256, 128, 2},    // enc.conv3 input gradient     60 (65)
-    {1, 2, 4, 256, 256, 2},    // dec.deconv1 forward          61 (76)
-    {0, 2, 8, 256, 256, 0},    // dec.deconv1 input gradient   69 (87)
-    {1, 1, 8, 256, 128, 2},    // dec.deconv2 forward         101 (145)
-    {0, 1, 8, 128, 256, 3},    // dec.deconv2 input gradient  100 (135)
-    {1, 2, 8, 128, 128, 5},    // dec.deconv3 forward          73 (92)
-    {0, 2, 17, 128, 128, 2},   // dec.deconv3 input gradient   57 (82)
-    {1, 1, 17, 128, 64, 4},    // dec.deconv4 forward         165 (186)
-    {0, 1, 19, 64, 128, 5},    // dec.deconv4 input gradient  144 (183)
-    {1, 2, 19, 64, 64, -1},    // dec.deconv5 forward         142 > 141
-    {0, 2, 39, 64, 64, 4},     // dec.deconv5 input gradient  113 (131)
+    {0, 2, 20, 64, 128, 5},    // enc.conv2 forward            53 us (fp32 MFMA kernel: 80)
+    {1, 2, 10, 128, 64, 6},    // enc.conv2 input gradient     60 (73)
+    {0, 2, 10, 128, 256, 2},   // enc.conv3 forward            48 (70)
+    {1, 2, 5, 256, 128, 6},    // enc.conv3 input gradient     55 (64)
+    {1, 2, 4, 256, 256, 2},    // dec.deconv1 forward          59 (74)
+    {0, 2, 8, 256, 256, 7},    // dec.deconv1 input gradient   62 (88)
+    {1, 1, 8, 256, 128, 2},    // dec.deconv2 forward         100 (137)
+    {0, 1, 8, 128, 256, 3},    // dec.deconv2 input gradient   99 (136)
+    {1, 2, 8, 128, 128, 5},    // dec.deconv3 forward          71 (91)
+    {0, 2, 17, 128, 128, 2},   // dec.deconv3 input gradient   57 (81)
+    {1, 1, 17, 128, 64, 8},    // dec.deconv4 forward         146 (180)
+    {0, 1, 19, 64, 128, 5},    // dec.deconv4 input gradient  125 (183)
+    {1, 2, 19, 64, 64, 6},     // dec.deconv5 forward         105-112 (138)
+    {0, 2, 39, 64, 64, 7},     // dec.deconv5 input gradient  104 (127)
 };
-static int x3_bm_of(int cfg) { return cfg == 0 ? 64 : (cfg == 2 || cfg == 5 || cfg == 6) ? 128 : 256; }
-static int x3_bn_of(int cfg) { return (cfg == 0 || cfg == 4 || cfg == 6) ? 64 : 128; }
+static int x3_bm_of(int cfg) { return cfg == 0 ? 64 : (cfg == 2 || cfg == 5 || cfg == 6 || cfg == 7) ? 128 : 256; }
+static int x3_bn_of(int cfg) { return (cfg == 0 || cfg == 4 || cfg == 6 || cfg == 7 || cfg == 8) ? 64 : 128; }
 int veex_gg_x3_cfg(const GGParams& p) {
   const long long M = (long long)p.Nb * p.Hout * p.Wout;
   int cfg = -2;
@@ -452,7 +526,7 @@ int veex_launch_gather_gemm_x3(GGParams& p, int mtiles, hipStream_t st) {
   if (3LL * p.kh * p.kw * p.Cin * p.Cout * 2 >= 0x7FFF0000LL) { veex_set_error("gather_gemm(x3): weights of 2 GiB or more"); return -1; }
   const int cfg = veex_gg_x3_cfg(p);
   if (cfg < 0) { veex_set_error("gather_gemm(x3): launch not taken"); return -1; }
-  const int bn = x3_bn_of(cfg), bk = (cfg == 3 || cfg == 5 || cfg == 6) ? 16 : 32;
+  const int bn = x3_bn_of(cfg), bk = (cfg == 3 || cfg == 5 || cfg == 6 || cfg == 8) ? 16 : 32;
   const int ntiles = (p.Cout + bn - 1) / bn;
   if (p.nsplit > 1) {
     const int nchunks = p.kh * p.kw * (p.Cin / bk);
@@ -468,6 +542,8 @@ int veex_launch_gather_gemm_x3(GGParams& p, int mtiles, hipStream_t st) {
     case 4: return m1 ? x3_launch<256, 64, 32, 4, 2, true>(p, grid, st) : x3_launch<256, 64, 32, 4, 2, false>(p, grid, st);
     case 5: return m1 ? x3_launch<128, 128, 16, 2, 2, true>(p, grid, st) : x3_launch<128, 128, 16, 2, 2, false>(p, grid, st);
     case 6: return m1 ? x3_launch<128, 64, 16, 2, 2, true>(p, grid, st) : x3_launch<128, 64, 16, 2, 2, false>(p, grid, st);
+    case 7: return m1 ? x3_launch<128, 64, 32, 2, 2, true>(p, grid, st) : x3_launch<128, 64, 32, 2, 2, false>(p, grid, st);
+    case 8: return m1 ? x3_launch<256, 64, 16, 4, 2, true>(p, grid, st) : x3_launch<256, 64, 16, 4, 2, false>(p, grid, st);
     default: return m1 ? x3_launch<64, 64, 32, 2, 2, true>(p, grid, st) : x3_launch<64, 64, 32, 2, 2, false>(p, grid, st);
   }
 }
