@@ -131,7 +131,9 @@ typedef struct VeexWgradDesc {
   int32_t kh, kw, stride, pad_begin;
   int32_t nsplit, rows_per_split;
   int32_t bf16;            /* 1: round both operands to bf16 while staging, bf16 MFMA, fp32 accumulate
-                              (rows_per_split multiple of 32, Cb % 4 == 0, Cs % 4 == 0) */
+                              (rows_per_split multiple of 32, Cb % 4 == 0, Cs % 4 == 0);
+                              2: fp32 result on the bf16 MFMA -- both operands split into three bf16 terms, six partial
+                              products per multiply, fp32 accumulate (kh*kw*Cb >= 65, else the fp32 MFMA) */
   const void* big_bf16;    /* optional bf16 consumer copies of big / small (BatchNorm already applied to the */
   const void* small_bf16;  /* activation side): both given + bf16=1 -> copy kernel (rows_per_split % 64 == 0) */
 } VeexWgradDesc;

@@ -288,3 +288,51 @@ def test_split_fp32_gather_kernel_equals_the_fp32_mfma_kernel(B):
             took += mt3 != mt
     del f32, keep32
     assert B < 512 or took >= 3        # at batch 512 the split kernel's own (taller) tiles ran
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [64, 512])
+def test_split_fp32_weight_gradient_kernel_equals_the_fp32_mfma_kernel(B):
+    """VeexWgradDesc::bf16 = 2 (wgrad_gemm_x3.hip: row-major three-term planes, transposing LDS reads, six bf16 MFMAs per
+    product) against the same launch on the fp32 MFMA, slab sums compared: an fp32 result (<= 5e-6 of the gradient's
+    max-abs; a bf16 launch differs by ~4e-3).  Every weight-gradient launch of the train step, with and without the
+    producer's BatchNorm on the operands."""
+    import ctypes as C
+    import torch
+    from vae_eeg_xai_amd import _lib, roofline as rl
+    from vae_eeg_xai_amd._lib import WgradDesc, check, lib
+    n = 0
+    for label, _, fn in rl.gemm_cases(B, False, x3=True):
+        if not label.endswith("wgrad"):
+            continue
+        d3 = fn.__defaults__[0]
+        assert d3.bf16 == 2
+        d = WgradDesc.from_buffer_copy(d3)
+        d.bf16 = 0
+        M = d.kh * d.kw * d.Cb
+        ref = torch.empty(d.nsplit * M * d.Cs, device="cuda")
+        out = torch.full((d3.nsplit * M * d3.Cs,), 7.0, device="cuda")
+        d.out, d3.out = ref.data_ptr(), out.data_ptr()
+        check(lib.veex_wgrad_gemm(C.byref(d), _lib.current_stream()), label)
+        check(lib.veex_wgrad_gemm(C.byref(d3), _lib.current_stream()), label)
+        torch.cuda.synchronize()
+        g, g3 = ref.view(d.nsplit, M, d.Cs).sum(0), out.view(d3.nsplit, M, d3.Cs).sum(0)
+        scale = g.abs().max().item()
+        assert scale > 0 and bool(torch.isfinite(g3).all()), label
+        assert (g3 - g).abs().max().item() <= 5e-6 * scale, label
+        n += 1
+        # the producer's BatchNorm applied while staging: on the tap-shifted operand (padding stays 0), then on the other
+        for side in ("big", "small"):
+            ch = d.Cb if side == "big" else d.Cs
+            sc, sh = torch.rand(ch, device="cuda") + 0.5, torch.randn(ch, device="cuda") * 0.1
+            for dd in (d, d3):
+                dd.big_scale = dd.big_shift = dd.small_scale = dd.small_shift = None
+                setattr(dd, side + "_scale", sc.data_ptr()); setattr(dd, side + "_shift", sh.data_ptr())
+                setattr(dd, side + "_affine_channels", ch)
+            check(lib.veex_wgrad_gemm(C.byref(d), _lib.current_stream()), label)
+            check(lib.veex_wgrad_gemm(C.byref(d3), _lib.current_stream()), label)
+            torch.cuda.synchronize()
+            g, g3 = ref.view(d.nsplit, M, d.Cs).sum(0), out.view(d3.nsplit, M, d3.Cs).sum(0)
+            assert (g3 - g).abs().max().item() <= 5e-6 * g.abs().max().item(), (label, side)
+    assert n == 6
+

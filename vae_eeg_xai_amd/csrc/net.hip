@@ -155,7 +155,9 @@ static int fill_wg(const VeexWgradDesc* d, WGParams& p) {
   p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pb = d->pad_begin;
   p.R = p.Nb * p.Hs * p.Ws;
   p.M = p.kh * p.kw * p.Cb;
-  p.nsplit = d->nsplit; p.rows_per_split = d->rows_per_split; p.bf16 = d->bf16;
+  p.nsplit = d->nsplit; p.rows_per_split = d->rows_per_split;
+  p.x3 = (d->bf16 == 2) ? 1 : 0;                 // 2: split-fp32 (fp32 results on the bf16 MFMA)
+  p.bf16 = p.x3 ? 0 : d->bf16;
   p.BigBf = d->big_bf16; p.SmallBf = d->small_bf16;
   if (p.Big == nullptr || p.Small == nullptr || p.Out == nullptr) { veex_set_error("wgrad: null operand"); return VEEX_EINVAL; }
   return 0;
@@ -461,7 +463,8 @@ extern "C" int veex_wgrad_plan(const VeexWgradDesc* d, int32_t* nsplit, int32_t*
   p.Nb = d->N; p.Hb = d->Hb; p.Wb = d->Wb; p.Cb = d->Cb; p.Hs = d->Hs; p.Ws = d->Ws; p.Cs = d->Cs;
   p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pb = d->pad_begin;
   p.R = p.Nb * p.Hs * p.Ws; p.M = p.kh * p.kw * p.Cb;
-  p.bf16 = d->bf16 ? ((d->big_bf16 != nullptr && d->small_bf16 != nullptr) ? 2 : 1) : 0;
+  p.x3 = (d->bf16 == 2) ? 1 : 0;
+  p.bf16 = (d->bf16 && !p.x3) ? ((d->big_bf16 != nullptr && d->small_bf16 != nullptr) ? 2 : 1) : 0;
   if (p.R < 1 || p.M < 1 || p.Cs < 1) { veex_set_error("wgrad_plan: bad geometry"); return VEEX_EINVAL; }
   const SplitPlan s = wgrad_split(p);
   *nsplit = s.nsplit; *rows_per_split = s.per;
@@ -501,17 +504,18 @@ static long long act_floats(const ConvLayer& c, int B) { return (long long)B * c
 static void wg_desc_deconv(const VeexNet* n, int i, int B, WGParams& p) {
   const ConvLayer& c = n->dc[i];
   memset(&p, 0, sizeof(p));
-  // 2: both operands come as bf16 consumer copies.  (The split-fp32 engine keeps its weight gradients on the fp32 MFMA:
-  // two split weight-gradient kernels were measured: 20-75 % slower than wgrad_gemm_v3.hip, then on a par with it but
-  // unable to share a CU with the split gather kernel, profiles/r03_x3_wgrad.txt, r03_x3_specialised.txt)
+  // 2: both operands come as bf16 consumer copies.  The split-fp32 engine runs wgrad_gemm_x3.hip (row-major planes read
+  // through the transposing LDS read; two earlier split kernels that transposed while staging were 20-75 % slower than
+  // wgrad_gemm_v3.hip, then on a par with it: profiles/r03_x3_wgrad.txt)
   p.bf16 = (n->compute == VEEX_COMPUTE_BF16) ? 2 : 0;
+  p.x3 = (n->compute == VEEX_COMPUTE_F32X3) ? 1 : 0;
   p.Nb = B; p.Hb = c.Hout; p.Wb = c.Hout; p.Cb = c.Cout; p.Hs = c.Hin; p.Ws = c.Hin; p.Cs = c.Cin;
   p.kh = c.k; p.kw = c.k; p.stride = c.stride; p.pb = c.pb;
   p.R = B * c.Hin * c.Hin; p.M = c.k * c.k * c.Cout;
 }
-static void wg_desc_conv(const ConvLayer& c, int B, WGParams& p, int bf16 = 0) {
+static void wg_desc_conv(const ConvLayer& c, int B, WGParams& p, int bf16 = 0, int x3 = 0) {
   memset(&p, 0, sizeof(p));
-  p.bf16 = bf16;
+  p.bf16 = bf16; p.x3 = x3;
   p.Nb = B; p.Hb = c.Hin; p.Wb = c.Hin; p.Cb = c.Cin; p.Hs = c.Hout; p.Ws = c.Hout; p.Cs = c.Cout;
   p.kh = c.k; p.kw = c.k; p.stride = c.stride; p.pb = c.pb;
   p.R = B * c.Hout * c.Hout; p.M = c.k * c.k * c.Cin;
@@ -572,7 +576,7 @@ static void make_plan(const VeexNet* n, int B, Plan& P) {
   auto upd = [](long long& m, long long v) { if (v > m) m = v; };
   WGParams wp;
   for (int i = 0; i < 5; ++i) { wg_desc_deconv(n, i, B, wp); upd(slab, (long long)wgrad_split(wp).nsplit * wp.M * wp.Cs); }
-  for (int i = 1; i < 3; ++i) { wg_desc_conv(n->conv[i], B, wp, n->compute == VEEX_COMPUTE_BF16 ? 2 : 0); upd(slab, (long long)wgrad_split(wp).nsplit * wp.M * wp.Cs); }
+  for (int i = 1; i < 3; ++i) { wg_desc_conv(n->conv[i], B, wp, n->compute == VEEX_COMPUTE_BF16 ? 2 : 0, n->compute == VEEX_COMPUTE_F32X3 ? 1 : 0); upd(slab, (long long)wgrad_split(wp).nsplit * wp.M * wp.Cs); }
   wg_desc_conv(n->dense, B, wp); upd(slab, (long long)wgrad_split(wp).nsplit * wp.M * wp.Cs);
   wg_desc_conv(n->ddense, B, wp); upd(slab, (long long)wgrad_split(wp).nsplit * wp.M * wp.Cs);
   if (n->variant == VEEX_VARIANT_VAE) {
@@ -1030,7 +1034,7 @@ static int encoder_backward(Ctx& c, const float* x, float* G, int want_param_gra
   for (int i = 2; i >= 1; --i) {
     const ConvLayer& l = n->conv[i];
     if (want_param_grads) {
-      WGParams w; wg_desc_conv(l, c.B, w, n->compute == VEEX_COMPUTE_BF16 ? 2 : 0);
+      WGParams w; wg_desc_conv(l, c.B, w, n->compute == VEEX_COMPUTE_BF16 ? 2 : 0, n->compute == VEEX_COMPUTE_F32X3 ? 1 : 0);
       w.Big = ws + P.act_conv[i - 1]; w.Small = ws + P.d_conv[i];
       w.BigBf = bfp(c, P.bf_act_conv[i - 1]); w.SmallBf = bfp(c, P.bf_d_conv[i]);
       w.b_scale = c.scale(n->conv[i - 1].bn); w.b_shift = c.shift(n->conv[i - 1].bn); w.b_aff_mask = n->conv[i - 1].Cout - 1;

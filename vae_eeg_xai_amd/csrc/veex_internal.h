@@ -87,6 +87,7 @@ struct WGParams {
   const void* SmallBf;   // activation side): staged with 16-byte copies + an in-register 8x8 transpose
   int gx, gy, gz;        // logical grid (m tiles, n tiles, row splits), filled by the launcher
   int remap;
+  int x3;                // 1 (bf16 == 0): fp32 results from three-term bf16 splits on the bf16 MFMA (wgrad_gemm_x3.hip)
 };
 
 // Logical block coordinates of a 1-D launch, XCD-aware: workgroups are placed round-robin over the
@@ -142,6 +143,8 @@ struct ColsumBatch { int n; ColsumEntry e[VEEX_COLSUM_MAX]; };
 int veex_colsum_batch(ColsumBatch& b, float* scratch, long long scratch_n, hipStream_t st);   // special.hip
 int veex_wgrad_v3_ok(const WGParams& p);                         // wgrad_gemm_v3.hip
 int veex_launch_wgrad_v3(const WGParams& p, int bm, int bn, hipStream_t st);
+int veex_wgrad_x3_ok(const WGParams& p, int bm, int bn);         // wgrad_gemm_x3.hip
+int veex_launch_wgrad_x3(const WGParams& p, int bm, int bn, hipStream_t st);
 int veex_launch_wgrad_bf16(const WGParams& p, hipStream_t st);
 extern "C" int veex_conv1_fwd_bf16(const float* x, const float* W, const float* bias, float* out, const float* bn_scale,
                                    const float* bn_shift, void* out_bf16, int B, hipStream_t st);

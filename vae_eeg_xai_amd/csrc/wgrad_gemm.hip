@@ -445,6 +445,7 @@ int veex_launch_wgrad(const WGParams& p, hipStream_t st) {
                     p.R < (1 << 24) && !(p.b_scale != nullptr && p.b_aff_spatial) &&
                     !(p.b_scale != nullptr && p.s_scale != nullptr) &&
                     (p.s_scale == nullptr || !p.s_aff_spatial || (p.s_aff_mask + 1) == p.Hs * p.Ws * p.Cs);
+  if (fast && veex_wgrad_x3_ok(p, bm, bn)) return veex_launch_wgrad_x3(p, bm, bn, st);
   if (fast && veex_tune_int("VEEX_WGV3", 1) && veex_wgrad_v3_ok(p)) return veex_launch_wgrad_v3(p, bm, bn, st);
   if (bm == 128 && bn == 128) return wg_launch_cfg<128, 128>(p, fast, st);
   if (bm == 128 && bn == 64) return wg_launch_cfg<128, 64>(p, fast, st);

@@ -91,7 +91,7 @@ def _pack3(W, transpose):
 
 def gemm_cases(B, bf16=False, x3=False):
     """Yield (label, macs, launch_fn) for every MFMA launch of one train step at batch B.  x3: the split-fp32 engine
-    (forward and input-gradient launches carry the three-plane weights; weight gradients are the fp32 engine's)."""
+    (forward and input-gradient launches carry the three-plane weights, weight gradients ask for the split kernel)."""
     stream = _lib.current_stream
     keep = []
     # fp32 engine: producers write a BatchNorm-applied fp32 copy (VeexGemmDesc::out_bn) and consumers read it without an
@@ -158,7 +158,7 @@ def gemm_cases(B, bf16=False, x3=False):
         d.kh = d.kw = k
         d.stride, d.pad_begin = stride, pb
         M = k * k * Cb
-        d.bf16 = 1 if bf16 else 0
+        d.bf16 = 1 if bf16 else (2 if x3 else 0)     # 2: the split-fp32 weight-gradient kernel
         if bf16:
             bb = (big * aff_big[0] + aff_big[1]) if aff_big is not None else big
             sb = (small * aff_small[0] + aff_small[1]) if aff_small is not None else small
@@ -238,7 +238,7 @@ def layer_table(B=512, iters=10, bf16=False, x3=False):
     MFMAs per product (416.7 TFLOP/s of fp32 work), its weight gradients against the fp32 MFMA peak they run on."""
     rows = []
     for label, macs, fn in gemm_cases(B, bf16, x3):
-        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else (PEAK_X3_TFLOPS if (x3 and not label.endswith("wgrad")) else PEAK_F32_MFMA_TFLOPS)
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else (PEAK_X3_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS)
         t = _time_launch(fn, iters)
         tf = 2.0 * macs / t / 1e12
         nbytes = algorithmic_bytes(label, B, bf16)
@@ -450,7 +450,7 @@ if __name__ == "__main__":
     x3 = len(sys.argv) > 2 and sys.argv[2] == "f32x3"
     tot = 0.0
     print(f"MFMA launches of one train step at batch {B} ({'bf16' if bf else 'split-fp32' if x3 else 'fp32'} engine), HIP-event time per launch; roof = "
-          f"max(FLOP / {'2500' if bf else '416.7 (forward, input gradient: 6 bf16 MFMAs per product) or 157.3 (weight gradient)' if x3 else '157.3'} TFLOP/s, algorithmic bytes / 8 TB/s)")
+          f"max(FLOP / {'2500' if bf else '416.7 (6 bf16 MFMAs per product)' if x3 else '157.3'} TFLOP/s, algorithmic bytes / 8 TB/s)")
     for r in layer_table(B, bf16=bf, x3=x3):
         tot += r["us"]
         print(f"{r['kernel']:22s} {r['us']:8.1f} us  {r['tflops']:6.1f} TF  {100 * r['frac']:5.1f}% of {'bf16' if bf else 'its' if x3 else 'f32'} MFMA peak"
