@@ -66,8 +66,8 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const WGParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* As = smem;                                     // [buf][plane][BK][BM] bf16
   unsigned char* Bs = smem + 2 * 3 * A_PL;                      // [buf][plane][BK][BN] bf16
-  int2* tab = reinterpret_cast<int2*>(Bs + 2 * 3 * B_PL);       // [nchunks * BK] (row byte offset, inverted tap mask)
-  int* tabS = reinterpret_cast<int*>(tab + ((p.rows_per_split + BK - 1) / BK) * BK);   // AFFS == 2: byte offset of the row's pixel in the affine
+  int* tab = reinterpret_cast<int*>(Bs + 2 * 3 * B_PL);         // [nchunks * BK] packed rows (below)
+  int* tabS = tab + ((p.rows_per_split + BK - 1) / BK) * BK;   // AFFS == 2: byte offset of the row's pixel in the affine
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -81,31 +81,35 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const WGParams p) {
   const int r_end = min(p.R, r_begin + p.rows_per_split);
   const int nchunks = (r_end > r_begin) ? (r_end - r_begin + BK - 1) / BK : 0;
 
-  // ---- row table (wgrad_gemm_v3.hip) ----
-  {
-    const int HWs = p.Hs * p.Ws;
-    const float invHWs = 1.0f / (float)HWs, invWs = 1.0f / (float)p.Ws;   // rows < 2^24 (veex_wgrad_x3_ok)
-    for (int t = tid; t < nchunks * BK; t += 256) {
-      const int r = r_begin + t;
-      int off = 0;
-      unsigned inv = 0xFFFFFFFFu;
-      if (r < r_end) {
-        int n = (int)((float)r * invHWs), rem = r - n * HWs;
-        if (rem < 0) { n -= 1; rem += HWs; }
-        if (rem >= HWs) { n += 1; rem -= HWs; }
-        int py = (int)((float)rem * invWs), px = rem - py * p.Ws;
-        if (px < 0) { py -= 1; px += p.Ws; }
-        if (px >= p.Ws) { py += 1; px -= p.Ws; }
-        const int y0 = p.stride * py - p.pb, x0 = p.stride * px - p.pb;
-        off = (((n * p.Hb + y0) * p.Wb + x0) * p.Cb) * 4;   // may be "virtual" (negative) at the border
-        unsigned xb = 0u, mk = 0u;
-        for (int kx = 0; kx < p.kw; ++kx) if (x0 + kx >= 0 && x0 + kx < p.Wb) xb |= 1u << kx;
-        for (int ky = 0; ky < p.kh; ++ky) if (y0 + ky >= 0 && y0 + ky < p.Hb) mk |= xb << (ky * p.kw);
-        inv = ~mk;
-      }
-      tab[t] = make_int2(off, (int)inv);
-      if (AFFS == 2) tabS[t] = (r % HWs) * p.Cs * 4;
+  // ---- row table (the idea of wgrad_gemm_v3.hip, 4 bytes per row so that 1 200 rows still leave room for three workgroups
+  // per CU): (pixel under tap (0,0) minus the pixel of the split's first row) << 9 | inverted tap-validity mask ----
+  const int HWs = p.Hs * p.Ws;
+  const float invHWs = 1.0f / (float)HWs, invWs = 1.0f / (float)p.Ws;   // rows < 2^24 (veex_wgrad_x3_ok)
+  auto row_pixel = [&](int r, int& y0, int& x0) {
+    int n = (int)((float)r * invHWs), rem = r - n * HWs;
+    if (rem < 0) { n -= 1; rem += HWs; }
+    if (rem >= HWs) { n += 1; rem -= HWs; }
+    int py = (int)((float)rem * invWs), px = rem - py * p.Ws;
+    if (px < 0) { py -= 1; px += p.Ws; }
+    if (px >= p.Ws) { py += 1; px -= p.Ws; }
+    y0 = p.stride * py - p.pb; x0 = p.stride * px - p.pb;
+    return (n * p.Hb + y0) * p.Wb + x0;        // may be "virtual" (negative / outside its image) at the border
+  };
+  int y0b, x0b;
+  const int pix_base = row_pixel(min(r_begin, p.R - 1), y0b, x0b);     // (block-uniform)
+  for (int t = tid; t < nchunks * BK; t += 256) {
+    const int r = r_begin + t;
+    int e = 0x1FF;
+    if (r < r_end) {
+      int y0, x0;
+      const int pix = row_pixel(r, y0, x0);
+      unsigned xb = 0u, mk = 0u;
+      for (int kx = 0; kx < p.kw; ++kx) if (x0 + kx >= 0 && x0 + kx < p.Wb) xb |= 1u << kx;
+      for (int ky = 0; ky < p.kh; ++ky) if (y0 + ky >= 0 && y0 + ky < p.Hb) mk |= xb << (ky * p.kw);
+      e = ((pix - pix_base) << 9) | (int)(~mk & 0x1FFu);
     }
+    tab[t] = e;
+    if (AFFS == 2) tabS[t] = (r % HWs) * p.Cs * 4;
   }
 
   const __amdgpu_buffer_rsrc_t rBig = __builtin_amdgcn_make_buffer_rsrc(
@@ -117,10 +121,12 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const WGParams p) {
   const int amq = tid % QM, arow = tid / QM;
   const int am = m0 + 4 * amq;
   const bool am_ok = am < p.M;
-  const int atap = am_ok ? am / p.Cb : 31;          // bit 31 of every mask is set: zeros
+  const int atap = am_ok ? am / p.Cb : 0;
+  const unsigned a_dead = am_ok ? 0u : 0xFFFFFFFFu;  // a thread past M loads zeros
   const int acb = am - (am / p.Cb) * p.Cb;
   const int aky = atap / p.kw, akx = atap - aky * p.kw;
-  const int a_const = am_ok ? ((aky * p.Wb + akx) * p.Cb + acb) * 4 : 0;
+  const int cb4 = p.Cb * 4;
+  const int a_const = am_ok ? (pix_base * p.Cb + (aky * p.Wb + akx) * p.Cb + acb) * 4 : 0;
   // ---- B loader ----
   const int bnq = tid % QN, brow = tid / QN;
   const int bn = n0 + 4 * bnq;
@@ -181,12 +187,12 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const WGParams p) {
   unsigned akeep[APASS];   // AFFB: all ones where the pixel is real (the BatchNorm shift applies), else 0
 
   auto load_chunk = [&](int c) {
-    const int2* tp = tab + c * BK + arow;
+    const int* tp = tab + c * BK + arow;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
-      const int2 e = tp[RPA * i];
-      const unsigned m = (unsigned)__builtin_amdgcn_sbfe(e.y, atap, 1);   // 0 or 0xFFFFFFFF
-      ra[i] = wxload(rBig, (unsigned)(e.x + a_const) | m, 0);
+      const int e = tp[RPA * i];
+      const unsigned m = (unsigned)__builtin_amdgcn_sbfe(e, atap, 1) | a_dead;   // 0 or 0xFFFFFFFF
+      ra[i] = wxload(rBig, (unsigned)(__mul24(e >> 9, cb4) + a_const) | m, 0);
       if (AFFB) akeep[i] = ~m;
     }
     const int soff = (r_begin + c * BK) * p.Cs * 4;
@@ -314,10 +320,10 @@ static int wgx_launch(const WGParams& pin, hipStream_t st) {
   const int tab_rows = (p.rows_per_split + VEEX_BK - 1) / VEEX_BK * VEEX_BK;
   const bool affb = p.b_scale != nullptr;
   const int affs = (p.s_scale == nullptr) ? 0 : (p.s_aff_spatial ? 2 : 1);
-  const size_t lds = (size_t)2 * 3 * VEEX_BK * (BM + BN) * 2 + (size_t)tab_rows * (sizeof(int2) + (affs == 2 ? sizeof(int) : 0));
+  const size_t lds = (size_t)2 * 3 * VEEX_BK * (BM + BN) * 2 + (size_t)tab_rows * (sizeof(int) + (affs == 2 ? sizeof(int) : 0));
   static bool attr_done = false;   // function attributes are per process; set them once, outside any capture
   if (!attr_done) {
-    const int cap = 2 * 3 * VEEX_BK * (BM + BN) * 2 + VEEX_WG3_MAX_ROWS * 12;
+    const int cap = 2 * 3 * VEEX_BK * (BM + BN) * 2 + VEEX_WG3_MAX_ROWS * 8;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<BM, BN, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<BM, BN, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_x3_kernel<BM, BN, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap) != hipSuccess ||
@@ -338,6 +344,8 @@ static int wgx_launch(const WGParams& pin, hipStream_t st) {
 int veex_wgrad_x3_ok(const WGParams& p, int bm, int bn) {
   if (!p.x3 || p.bf16) return 0;
   if (bm != 128 || (bn != 128 && bn != 64)) return 0;
+  if (p.kh * p.kw > 9 || p.Cb > 4096) return 0;          // 9 mask bits per table row; the row's pixel delta times Cb * 4 in 24-bit operands
+  if ((long long)p.rows_per_split * p.stride * p.stride + 4LL * p.Wb * (p.kh + p.stride) >= (1LL << 21)) return 0;   // pixel delta within a split
   return veex_wgrad_v3_ok(p);
 }
 
