@@ -349,9 +349,9 @@ def main():
                                     f"{n_local} synthetic 40x40 topomaps resident per GPU, ") +
                                    f"latent {L}, Adam lr 1e-5, " +
                                    {"f32": "fp32 (fp32 MFMA instructions)",
-                                    "f32x3": "fp32 results, split-fp32 engine: the conv / deconv forward and input-gradient GEMMs "
-                                             "on the bf16 matrix cores from three-term operand splits (six partial products, fp32 "
-                                             "accumulate), weight gradients and small layers on the fp32 MFMA; 1e-5 parity bar",
+                                    "f32x3": "fp32 results, split-fp32 engine: the conv / deconv forward, input-gradient and "
+                                             "weight-gradient GEMMs on the bf16 matrix cores from three-term operand splits (six "
+                                             "partial products, fp32 accumulate), the small layers on the fp32 MFMA; 1e-5 parity bar",
                                     "bf16": "bf16 MFMA (fp32 accumulate / storage / master weights)"}[args.dtype],
                        "engine": args.dtype,
                        "global_batch": B * world, "local_batch": B, "latent": L, "parallelism": f"dp{world}",
@@ -373,7 +373,7 @@ def main():
         if f32_mfma is not None:
             out["f32_mfma"] = f32_mfma
         if args.dtype == "f32x3":
-            out["frac_mfma_peak_note"] = ("fp32 FLOP of the step / 157.3 TFLOP/s, the fp32 MFMA instruction's peak; 12 of the 21 large "
+            out["frac_mfma_peak_note"] = ("fp32 FLOP of the step / 157.3 TFLOP/s, the fp32 MFMA instruction's peak; the 20 large "
                                           "GEMM launches run on the bf16 pipe instead (roofline.peak_note)")
         if not args.no_roofline:
             out["roofline"] = rl.dominant_kernel_roofline(net, B)

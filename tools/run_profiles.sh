@@ -13,7 +13,7 @@ timeout -k 10 120 python -m vae_eeg_xai_amd.roofline 512 f32x3 > $O/layer_table_
 timeout -k 10 300 python bench.py --dtype bf16 --steps 50 --warmup 10 --no-cpu-baseline > $O/bench_bf16.json 2> $O/bench_bf16.err
 timeout -k 10 300 python bench.py --dtype f32 --steps 50 --warmup 10 --no-cpu-baseline --no-bf16 > $O/bench_f32_mfma.json 2> $O/bench_f32_mfma.err
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-attribution --no-bf16 > $O/trace.log 2>&1
-# split-fp32 engine: counter passes over ITS launches (forward / input gradient on the split kernel, weight gradients fp32)
+# split-fp32 engine: counter passes over ITS launches (forward, input gradient and weight gradient on the split kernels)
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_x3 -- python tools/prof_gemms.py 512 2 f32x3 > $O/pmc_fetch_x3.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_x3 -- python tools/prof_gemms.py 512 2 f32x3 > $O/pmc_write_x3.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq_x3 -- python tools/prof_gemms.py 512 2 f32x3 > $O/pmc_sq_x3.log 2>&1

@@ -305,7 +305,7 @@ def dominant_kernel_roofline(net, batch):
         tf = 2.0 * macs / t / 1e12
         # the committed counter passes were taken at batch 512 (tools/run_profiles.sh)
         traffic = _pmc_traffic("dec.deconv4.fwd", bf16, x3) if batch == 512 else None
-        kname = "gather_gemm_bf16_kernel" if bf16 else "gather_gemm_x3_kernel<256, 64, 32>" if x3 else "gather_gemm_v3_kernel"
+        kname = "gather_gemm_bf16_kernel" if bf16 else "gather_gemm_x3_kernel<256, 64, 16> (722 workgroups of 8 waves, two per CU)" if x3 else "gather_gemm_v3_kernel"
         best = {"bound": "mfma", "kernel": kname + " mode 1 (dec.deconv4 forward, Conv2DTranspose 128->64 k3 s1)",
                 "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                 "traffic": traffic, "traffic_source": _PMC_NOTE if traffic is not None else None, "us_per_launch": t * 1e6,
