@@ -445,7 +445,10 @@ static SplitPlan wgrad_split(const WGParams& pin) {
   // (the bf16 copy kernel holds 72 KB of LDS: 2 blocks per CU)
   // (bf16 copy kernel, 72 KB of LDS: ONE block per CU measured best inside the step -- 1.209 -> 1.176 ms at batch 512
   //  against two per CU, -0.8 % at batch 2 048: half the slab bytes, and the input-gradient launches keep the other slot)
-  const int target = veex_tune_int("VEEX_WG_BLOCKS", (pin.bf16 == 2) ? 256 : 768);
+  // (transposing-read bf16 kernel, wgrad_gemm_bf16t.hip, 64 KB + row table: two per CU -- 512 and 768 measure the same
+  //  inside the step, 256 is 6 % slower on it; profiles/r03_bf16_wgrad_tr.txt)
+  const bool bt = pin.bf16 == 2 && veex_tune_int("VEEX_WGBT", 1) != 0;
+  const int target = veex_tune_int("VEEX_WG_BLOCKS", (pin.bf16 == 2) ? (bt ? 512 : 256) : 768);
   int ns = veex_tune_int("VEEX_WG_FLOOR", 1) ? target / tiles : (target + tiles - 1) / tiles;
   const int maxs = (chunks / 4 > 0) ? chunks / 4 : 1;
   if (ns > maxs) ns = maxs;
@@ -453,6 +456,7 @@ static SplitPlan wgrad_split(const WGParams& pin) {
   const int cps = (chunks + ns - 1) / ns;
   SplitPlan s; s.per = cps * bk;
   if (!pin.bf16 && s.per > VEEX_WG3_MAX_ROWS) s.per = VEEX_WG3_MAX_ROWS;   // keep the lean kernel's row table in LDS
+  if (bt && s.per > VEEX_WGT_MAX_ROWS) s.per = VEEX_WGT_MAX_ROWS;          // and the transposing-read bf16 kernel's
   s.nsplit = (pin.R + s.per - 1) / s.per;
   return s;
 }

@@ -127,6 +127,7 @@ int veex_gg_bf16_only(const GGParams& p);   // gather_gemm.hip: 0 no, 1 reads on
 int veex_wgrad_bf16c_ok(const WGParams& p);  // wgrad_gemm_bf16.hip: the copy kernel (reads only the two bf16 copies) takes it
 int veex_wg_tiles(const WGParams& p, int* bm, int* bn);
 int veex_wgrad_bf16_ok(const WGParams& p);                       // wgrad_gemm_bf16.hip
+#define VEEX_WGT_MAX_ROWS 4096                                    // rows_per_split the LDS row table of wgrad_gemm_bf16t.hip holds (16 KB)
 #define VEEX_WG3_MAX_ROWS 3072                                    // rows_per_split the LDS row table of wgrad_gemm_v3.hip holds
 #define VEEX_PARTIALS2_N (256LL * 768)   // floats: 256 compacted rows of 3 x 256 channels (one entry of veex_colsum_batch)
 // Every column-sum finalisation of one backward pass in two launches (instead of up to 17 of ~5 us each):
@@ -143,6 +144,8 @@ struct ColsumBatch { int n; ColsumEntry e[VEEX_COLSUM_MAX]; };
 int veex_colsum_batch(ColsumBatch& b, float* scratch, long long scratch_n, hipStream_t st);   // special.hip
 int veex_wgrad_v3_ok(const WGParams& p);                         // wgrad_gemm_v3.hip
 int veex_launch_wgrad_v3(const WGParams& p, int bm, int bn, hipStream_t st);
+int veex_wgrad_bf16t_ok(const WGParams& p);                      // wgrad_gemm_bf16t.hip (p passes veex_wgrad_bf16c_ok)
+int veex_launch_wgrad_bf16t(const WGParams& p, hipStream_t st);
 int veex_wgrad_x3_ok(const WGParams& p, int bm, int bn);         // wgrad_gemm_x3.hip
 int veex_launch_wgrad_x3(const WGParams& p, int bm, int bn, hipStream_t st);
 int veex_launch_wgrad_bf16(const WGParams& p, hipStream_t st);

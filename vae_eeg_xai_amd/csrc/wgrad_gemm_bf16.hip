@@ -450,7 +450,10 @@ int veex_wgrad_bf16c_ok(const WGParams& p) {
 }
 
 int veex_launch_wgrad_bf16(const WGParams& p, hipStream_t st) {
-  if (veex_wgrad_bf16c_ok(p)) return (p.Cs > 64) ? wgbc_launch<128, 128>(p, st) : wgbc_launch<128, 64>(p, st);
+  if (veex_wgrad_bf16c_ok(p)) {
+    if (veex_wgrad_bf16t_ok(p)) return veex_launch_wgrad_bf16t(p, st);     // no transpose while staging (wgrad_gemm_bf16t.hip)
+    return (p.Cs > 64) ? wgbc_launch<128, 128>(p, st) : wgbc_launch<128, 64>(p, st);
+  }
   if (p.Cs > 64) return wgb_launch<128, 128>(p, st);
   return wgb_launch<128, 64>(p, st);
 }
