@@ -448,7 +448,9 @@ static SplitPlan wgrad_split(const WGParams& pin) {
   // (transposing-read bf16 kernel, wgrad_gemm_bf16t.hip, 64 KB + row table: two per CU -- 512 and 768 measure the same
   //  inside the step, 256 is 6 % slower on it; profiles/r03_bf16_wgrad_tr.txt)
   const bool bt = pin.bf16 == 2 && veex_tune_int("VEEX_WGBT", 1) != 0;
-  const int target = veex_tune_int("VEEX_WG_BLOCKS", (pin.bf16 == 2) ? (bt ? 512 : 256) : 768);
+  // (split-fp32 kernel, wgrad_gemm_x3.hip: 768 = three per CU is its best stand-alone, 512 is 1.1 % better on the step --
+  //  the input-gradient launches of the main stream keep a slot; 384 / 640 / 1 024 are worse; profiles/r03_x3_wgrad.txt)
+  const int target = veex_tune_int("VEEX_WG_BLOCKS", (pin.bf16 == 2) ? (bt ? 512 : 256) : (pin.x3 ? 512 : 768));
   int ns = veex_tune_int("VEEX_WG_FLOOR", 1) ? target / tiles : (target + tiles - 1) / tiles;
   const int maxs = (chunks / 4 > 0) ? chunks / 4 : 1;
   if (ns > maxs) ns = maxs;
