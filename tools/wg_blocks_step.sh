@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box, tuning build: the row-split target of the weight-gradient GEMMs (VEEX_WG_BLOCKS) on the whole split-fp32 train step
+# (make -C vae_eeg_xai_amd/csrc timing first)  GPU box, tuning build: the row-split target of the weight-gradient GEMMs (VEEX_WG_BLOCKS) on the whole split-fp32 train step
 cd "${GRAFT_REPO_ROOT:-.}"
 cp vae_eeg_xai_amd/libveex_timing.so vae_eeg_xai_amd/libveex.so
 mkdir -p gpurun_out; : > gpurun_out/wg_blocks_step.txt

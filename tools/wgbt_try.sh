@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: bf16 tests with the shipped library, then (tuning build) the transposing-read bf16 weight-gradient kernel against
+# (make -C vae_eeg_xai_amd/csrc timing first)  GPU box: bf16 tests with the shipped library, then (tuning build) the transposing-read bf16 weight-gradient kernel against
 # the copy kernel: per-launch table rows and the bf16 step, over its chunk depth and the row-split target.
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out

@@ -1,6 +1,6 @@
 """Split-fp32 gather kernel with one ingredient removed at a time (VEEX_X3_DBG of a `make TIMING=1` build; the results of
 such a launch are wrong by construction): what each ingredient costs in the full loop.
-usage: VEEX_LIB=vae_eeg_xai_amd/libveex_timing.so python tools/x3_ablate.py [batch]"""
+usage: make -C vae_eeg_xai_amd/csrc timing; VEEX_LIB=vae_eeg_xai_amd/libveex_timing.so python tools/x3_ablate.py [batch]"""
 import ctypes as C
 import os
 import sys
