@@ -15,6 +15,7 @@
 // Tiles from 64 x 64 x 32 (4 waves) to 256 x 128 x 16 (8 waves, 74 KB of LDS: 3 planes x 2 buffers), chosen per layer;
 // LDS rows are unpadded with their 16-byte pieces XOR-swizzled by the row (no bank conflict on either side).
 #include "gg_common.h"
+#include <cstdio>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -486,7 +487,8 @@ static const X3Known X3_KNOWN[] = {
     {1, 2, 4, 256, 256, 2},    // dec.deconv1 forward          59 (74)
     {0, 2, 8, 256, 256, 7},    // dec.deconv1 input gradient   62 (88)
     {1, 1, 8, 256, 128, 2},    // dec.deconv2 forward         100 (137)
-    {0, 1, 8, 128, 256, 3},    // dec.deconv2 input gradient   99 (136)
+    {0, 1, 8, 128, 256, 5},    // dec.deconv2 input gradient  102 (136); tile 3 is 99 on its own, 5 is 0.8 % better on the step
+                               //   (49 KB of LDS beside the weight gradients of the side stream; tools/x3_step_tiles.sh)
     {1, 2, 8, 128, 128, 5},    // dec.deconv3 forward          71 (91)
     {0, 2, 17, 128, 128, 2},   // dec.deconv3 input gradient   57 (81)
     {1, 1, 17, 128, 64, 8},    // dec.deconv4 forward         146 (180)
@@ -503,7 +505,14 @@ int veex_gg_x3_cfg(const GGParams& p) {
   if (force >= -1 && !(p.Cout <= 64 && force >= 0 && x3_bn_of(force) == 128)) cfg = force;
   if (cfg == -2 && p.kh == 3 && p.kw == 3)
     for (const X3Known& e : X3_KNOWN)
-      if (e.mode == p.mode && e.stride == p.stride && e.Hin == p.Hin && e.Cin == p.Cin && e.Cout == p.Cout) cfg = e.cfg;
+      if (e.mode == p.mode && e.stride == p.stride && e.Hin == p.Hin && e.Cin == p.Cin && e.Cout == p.Cout) {
+        cfg = e.cfg;
+#ifdef VEEX_DEBUG_TIMING
+        char name[24];      // VEEX_X3_T<row of the table>: one layer's tile inside the whole step
+        snprintf(name, sizeof(name), "VEEX_X3_T%d", (int)(&e - X3_KNOWN));
+        cfg = veex_tune_int(name, cfg);
+#endif
+      }
   if (cfg == -1) return -1;
   // the table's tile (or the largest) only while it still gives every CU a workgroup; else smaller tiles
   auto blocks = [&](int c) { return ((M + x3_bm_of(c) - 1) / x3_bm_of(c)) * ((p.Cout + x3_bn_of(c) - 1) / x3_bn_of(c)); };
